@@ -1,0 +1,174 @@
+/*
+ * sugar_amd.h -- C-ABI of libsugar_amd.so: the MI355X (gfx950) embedding-extraction hot path of
+ * EfficientTDNN (mechanicalsea/sugar), hand-written HIP.
+ *
+ * The reference has no FFI / plugin registry: its boundary for this path is the Python call surface
+ * (SURVEY.md section 8b).  Every entry point below therefore cites the reference *function* it replaces
+ * (file:line relative to the reference root).  INTEGRATION.md shows the ctypes stub a sugar maintainer
+ * would add to bind them.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named d_* is a DEVICE pointer owned by the caller, h_* is a HOST pointer
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued, nothing syncs
+ *   - return 0 on success, negative SUGAR_E* on failure; sugar_last_error() gives the per-thread message
+ *   - activations are CHANNELS-LAST and PACKED over utterances: row r of a [R, C] buffer is one frame, utterance
+ *     b owns rows [row_off[b], row_off[b+1]);  R = row_off[B].  There is no padding between utterances, so
+ *     variable-length batches need no masks: every conv zero-pads at each utterance's true ends and every
+ *     reduction (instance norm, SE mean, attentive pooling) runs over each utterance's true frames.
+ *   - dtype: SUGAR_F32 = exact-f32 MFMA path (parity >= 0.9999 cosine), SUGAR_BF16 = bf16 operands with f32
+ *     accumulation (parity >= 0.999 cosine).  It selects the element type of feats / activations / weights.
+ */
+#ifndef SUGAR_AMD_H
+#define SUGAR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUGAR_F32 0
+#define SUGAR_BF16 1
+
+#define SUGAR_OK 0
+#define SUGAR_EINVAL (-1)   /* bad argument (shape, alignment, NULL)            */
+#define SUGAR_EHIP (-2)     /* a HIP runtime call failed                        */
+#define SUGAR_ENOMEM (-3)   /* workspace too small / allocation failed          */
+
+#define SUGAR_MAX_DEPTH 8
+#define SUGAR_RES2_SCALE 8  /* Res2 scale, sugar/models/dynamictdnn.py:384      */
+#define SUGAR_N_MELS 80
+#define SUGAR_HOP 160
+
+/* Per-thread message of the last failing call. */
+const char* sugar_last_error(void);
+/* Library version string; also a cheap "does the .so load" probe. */
+const char* sugar_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Subnet description: the tensors of `DynamicTDNN.clone(config).state_dict()`
+ * (sugar/models/dynamictdnn.py:713-730; key names in SURVEY.md Appendix A), as host float32 pointers in the
+ * reference's own layouts: conv weights [Cout][Cin][k], linear weights [out][in], BN as 4 vectors of length C.
+ * Weight materialisation (channel slices / gathers and the k53/k31 kernel transforms,
+ * sugar/modules/dynamicarch.py:411-432) happens in the host mirror before this call.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* weight;        /* gamma */
+  const float* bias;          /* beta  */
+  const float* running_mean;
+  const float* running_var;
+} SugarBN;
+
+typedef struct {
+  int mid_channels;           /* 8 * width: out channels of first_conv (dynamictdnn.py:410-411)            */
+  int kernel;                 /* Res2 conv kernel size: 1, 3 or 5                                          */
+  const float* first_w;       /* [mid][C0][1]    blocks.i.first_conv.conv.weight                           */
+  SugarBN first_bn;           /* [mid]                                                                     */
+  const float* res_w[SUGAR_RES2_SCALE - 1];   /* [w][w][kernel]  blocks.i.resconv.convs.j.conv.weight      */
+  SugarBN res_bn[SUGAR_RES2_SCALE - 1];       /* [w]                                                       */
+  const float* last_w;        /* [C0][mid][1]    blocks.i.last_conv.conv.weight                            */
+  SugarBN last_bn;            /* [C0]                                                                      */
+  const float* se_reduce_w;   /* [C0/4][C0]      blocks.i.se.reduce.weight                                 */
+  const float* se_reduce_b;   /* [C0/4]                                                                    */
+  const float* se_expand_w;   /* [C0][C0/4]      blocks.i.se.expand.weight                                 */
+  const float* se_expand_b;   /* [C0]                                                                      */
+} SugarBlock;
+
+typedef struct {
+  int in_feats;               /* 80                                                                        */
+  int embed_dim;              /* 192                                                                       */
+  int depth;                  /* number of SE-Res2 blocks (2..4 for tdnn8m2g)                              */
+  int c0;                     /* layer1 / block in-out channels                                            */
+  int k0;                     /* layer1 kernel size                                                        */
+  int ccat;                   /* catconv out channels                                                      */
+  int bottleneck;             /* attentive pooling bottleneck, 128 (dynamictdnn.py:494)                    */
+  const float* layer1_w;      /* [C0][in_feats][k0]   layer1.conv.weight                                   */
+  SugarBN layer1_bn;          /* [C0]                                                                      */
+  SugarBlock blocks[SUGAR_MAX_DEPTH];
+  const float* catconv_w;     /* [Ccat][depth*C0][1]  catconv.weight   (ReLU, no BN: dynamictdnn.py:663)   */
+  const float* pool1_w;       /* [bottleneck][Ccat][1] pooling.linear1.weight                              */
+  const float* pool2_w;       /* [Ccat][bottleneck][1] pooling.linear2.weight                              */
+  SugarBN bnpool;             /* [2*Ccat]                                                                  */
+  const float* linear_w;      /* [embed][2*Ccat]      linear.weight                                        */
+  const float* linear_b;      /* [embed]                                                                   */
+  SugarBN bnembed;            /* [embed]                                                                   */
+} SugarSubnetDesc;
+
+typedef struct SugarSubnet SugarSubnet;   /* opaque, library-owned packed weights on one device */
+
+/* Replaces: DynamicTDNN.clone() materialising static nn.Conv1d/BatchNorm1d/Linear leaves
+ * (dynamictdnn.py:713-730, dynamicarch.py:188-208, 320-339, 482-501) + `.to(device)`.
+ * Packs weights into MFMA-friendly [Cout][tap*Cin] panels (dtype), folds every eval-mode BN into a per-channel
+ * (scale, shift) epilogue applied AFTER the ReLU (conv -> ReLU -> BN, dynamictdnn.py:183), folds
+ * bnpool . linear . bnembed (dynamictdnn.py:664-665) into one affine map, and uploads to `device`.
+ * This call allocates device memory and synchronises; it is not on the per-batch path. */
+int sugar_subnet_create(const SugarSubnetDesc* h_desc, int dtype, int device, SugarSubnet** out);
+int sugar_subnet_destroy(SugarSubnet* net);
+
+/* Bytes of device workspace sugar_embed_fwd / sugar_tdnn_fwd need for B utterances totalling R frames. */
+int64_t sugar_workspace_bytes(const SugarSubnet* net, int B, int64_t R);
+
+/* Replaces: LogMelFbanks.forward (sugar/transforms.py:60-77) = PreEmphasis (:22-27) + torchaudio MelSpectrogram
+ * (:50-52; STFT n_fft 512, Hamming(400) periodic, hop 160, centre reflect pad, |.|^2, HTK mel 80 bins 20-7600 Hz)
+ * + 1e-6, log (:70-72) + InstanceNorm1d(80) (:47,73), as one fused DFT kernel plus a per-utterance normaliser.
+ *   d_wav      float32 samples of all utterances; utterance b = d_wav[wav_off[b] .. wav_off[b]+wav_len[b])
+ *   d_row_off  int32[B+1] frame offsets, row_off[b+1]-row_off[b] must equal 1 + wav_len[b]/160
+ *   d_logmel   float32 [R][80] scratch (log mel before normalisation)
+ *   d_feats    dtype   [R][80] output, channels-last (the reference returns [B,1,80,T])
+ *   t_max      max frames of any utterance (grid sizing) */
+int sugar_fbank_fwd(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
+                    const int32_t* d_row_off, int B, int t_max,
+                    float* d_logmel, void* d_feats, int dtype, void* stream);
+
+/* Replaces: DynamicTDNN.forward on a cloned subnet (dynamictdnn.py:645-666) [+ F.normalize(p=2) of
+ * sugar/vectors.py:143-144 when `normalize` != 0].
+ *   d_feats [R][80] dtype of the subnet;  d_emb float32 [B][embed_dim] */
+int sugar_tdnn_fwd(const SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R,
+                   int t_max, void* d_workspace, int64_t workspace_bytes, float* d_emb, int normalize,
+                   void* stream);
+
+/* Replaces: SpeakerModel.forward with a transform (sugar/models/__init__.py:79-114): waveforms -> embeddings.
+ * = sugar_fbank_fwd + sugar_tdnn_fwd on one stream, intermediate buffers in the workspace. */
+int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d_wav_off,
+                    const int32_t* d_wav_len, const int32_t* d_row_off, int B, int64_t R, int t_max,
+                    void* d_workspace, int64_t workspace_bytes, float* d_emb, int normalize, void* stream);
+
+/* Debug / parity tap: runs sugar_tdnn_fwd (un-normalised embeddings to d_emb) and additionally copies one
+ * intermediate activation, converted to float32, to d_out as [R][C] in the library's INTERNAL channel layout
+ * (channels padded to multiples of 8; Res2 groups padded per group -- see DESIGN.md "data layout").
+ * `what`: 0 layer1; 1+4*i+{0 first_conv, 1 res2, 2 last_conv, 3 block output} for block i; 100 catconv;
+ * 101 pooled statistics [B][2*Ccat_p]; 102 tanh(pooling.linear1) [R][128].
+ * Returns C (>0) or a negative error.  No reference counterpart: the reference exposes its nn.Modules directly
+ * (tests call sub.layer1(x), sub.blocks[i].first_conv(...) ...). */
+int sugar_tdnn_tap(const SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R,
+                   int t_max, void* d_workspace, int64_t workspace_bytes, int what, float* d_out,
+                   int64_t out_elems, float* d_emb, void* stream);
+
+/* Replaces: one DynamicConv1dReLUBN / DynamicConv1d forward (dynamictdnn.py:182-183, dynamicarch.py:401-409)
+ * on packed channels-last rows -- the implicit-GEMM MFMA kernel in isolation, for per-kernel parity tests.
+ *   h_w [Cout][Cin][k] host float32 (packed + uploaded inside: NOT a fast path), optional h_bn (NULL = no BN),
+ *   d_x [R][Cin] dtype (+ optional d_x2 added element-wise before the conv, NULL = none), d_y [R][Cout] dtype.
+ *   flags: bit0 ReLU, bit1 BN affine after ReLU, bit2 tanh.  Cin and Cout must be multiples of 8.
+ *   Allocates and synchronises internally. */
+int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, int k, int dilation, int flags,
+                     const void* d_x, const void* d_x2, void* d_y, const int32_t* d_row_off, int B, int64_t R,
+                     int t_max, int dtype, void* stream);
+
+/* Replaces: F.normalize(vec, p=2, dim=1) (sugar/vectors.py:108-109,143-144), in place, float32 [n][dim]. */
+int sugar_l2norm(float* d_x, int64_t n, int dim, void* stream);
+
+/* Replaces: score_trials' python loop over calculate_score(mode="cosine")
+ * (sugar/scores.py:146-150, 188-206): score[t] = mean over the n x m pairwise cosine similarities
+ * (F.cosine_similarity, eps 1e-8) of the enrol utterance's n segment vectors and the test utterance's m.
+ *   d_vec      float32 [n_rows][dim]      all segment vectors, utterance u owns rows [seg_off[u], seg_off[u+1])
+ *   d_seg_off  int32[n_utts+1]
+ *   d_enroll / d_test  int32[n_trials] utterance ids
+ *   d_scores   float32[n_trials] */
+int sugar_cosine_trials(const float* d_vec, int dim, const int32_t* d_seg_off, int n_utts,
+                        const int32_t* d_enroll, const int32_t* d_test, int64_t n_trials,
+                        float* d_scores, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUGAR_AMD_H */

@@ -1,0 +1,16 @@
+"""
+sugar_amd -- MI355X-native embedding-extraction path of EfficientTDNN (mechanicalsea/sugar).
+
+Python keeps sugar's call surface (WrappedModel.from_pretrained / subnet(wav) / extract_vectors / score_trials)
+and its checkpoint format; all device work is hand-written gfx950 HIP behind the C-ABI of include/sugar_amd.h.
+"""
+from .dynamictdnn import (DynamicTDNN, TDNNPath, TDNNSubnet, ecapa_tdnn, specfic_tdnn, tdnn8m2g, tdnn14m4g,
+                          tdnn16m4g, tdnn26m7g)
+from .models import SpeakerModel, WrappedModel, bn_state_dict, checkpoint2backbone
+from .scores import calculate_score, score_trials
+from .transforms import LogMelFbanks, PreEmphasis
+from .vectors import extract_vectors
+
+__all__ = ["DynamicTDNN", "TDNNPath", "TDNNSubnet", "ecapa_tdnn", "specfic_tdnn", "tdnn8m2g", "tdnn14m4g",
+           "tdnn16m4g", "tdnn26m7g", "SpeakerModel", "WrappedModel", "bn_state_dict", "checkpoint2backbone",
+           "calculate_score", "score_trials", "LogMelFbanks", "PreEmphasis", "extract_vectors"]

@@ -1,0 +1,161 @@
+// Shared helpers for libsugar_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sugar_amd.h"
+
+namespace sugar {
+
+void set_error(const char* fmt, ...);
+
+#define SUGAR_CHECK_ARG(cond, ...)      \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::sugar::set_error(__VA_ARGS__);  \
+      return SUGAR_EINVAL;              \
+    }                                   \
+  } while (0)
+
+#define SUGAR_HIP(call)                                                                     \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      ::sugar::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return SUGAR_EHIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+#define SUGAR_LAUNCH_CHECK()                                                                \
+  do {                                                                                      \
+    hipError_t e__ = hipGetLastError();                                                     \
+    if (e__ != hipSuccess) {                                                                \
+      ::sugar::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+      return SUGAR_EHIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+template <typename T>
+struct DT;
+template <>
+struct DT<float> {
+  static constexpr int id = SUGAR_F32;
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+};
+template <>
+struct DT<bf16> {
+  static constexpr int id = SUGAR_BF16;
+  static constexpr int EPC = 8;
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float x);
+template <>
+__device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+// host-side f32 -> bf16 bits, round to nearest even (weights are finite)
+static inline uint16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// ---- per-row utterance segment table ------------------------------------------------------------
+// rowseg[r] = (first row, one-past-last row) of the utterance owning row r.
+int launch_build_rowseg(const int32_t* d_row_off, int B, int t_max, int2* d_rowseg, hipStream_t s);
+
+// ---- implicit-GEMM conv (conv_gemm.hip) ---------------------------------------------------------
+enum { EPI_RELU = 1, EPI_AFFINE = 2, EPI_TANH = 4 };
+
+struct ConvLayer {       // packed, device-resident
+  void* w = nullptr;     // [n_pad][k_pad] dtype, K index = tap * cin_p + ci
+  float* scale = nullptr;  // [n_pad] (nullptr when no affine)
+  float* shift = nullptr;
+  int cout = 0;          // valid output channels (padded internal layout)
+  int n_pad = 0;         // rows of w
+  int cin_p = 0;         // padded input channels (row length of the activation slice read)
+  int ktaps = 1;
+  int dil = 1;
+  int k_pad = 0;
+  int flags = 0;
+};
+
+struct ConvIO {
+  const void* x = nullptr;   // [R][..] activation, column offset already applied
+  int ldx = 0;
+  const void* x2 = nullptr;  // optional addend, same shape
+  int ldx2 = 0;
+  void* y = nullptr;
+  int ldy = 0;
+  void* y2 = nullptr;        // optional duplicate store of columns >= y2_from (pointer has NO column offset)
+  int ldy2 = 0;
+  int y2_from = 0;
+};
+
+int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s);
+
+// Pack a reference-layout conv weight [cout][cin][k] (host f32) into ConvLayer storage with an internal channel
+// permutation / padding: out_map[o] = packed output row of reference channel o, in_map[i] = packed input
+// column of reference input channel i (nullptr = identity).  bn may be nullptr.
+int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int cin, int k, int dil, int flags,
+              int cout_p, const int* out_map, int cin_p, const int* in_map, int dtype);
+void free_conv(ConvLayer* L);
+
+// ---- front-end (fbank.hip) ----------------------------------------------------------------------
+int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
+                 int B, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s);
+
+// ---- SE / pooling / tail (se_pool.hip) ----------------------------------------------------------
+struct SELayer {            // device, f32, transposed for coalesced reads
+  float* w1t = nullptr;     // [c0_p][hid]   (reduce.weight^T)
+  float* b1 = nullptr;      // [hid]
+  float* w2t = nullptr;     // [hid][c0_p]   (expand.weight^T)
+  float* b2 = nullptr;      // [c0_p]
+  int c = 0, c_p = 0, hid = 0;
+};
+// scale[b][c] = sigmoid(W2 relu(W1 mean_t(y[b]) + b1) + b2)
+int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B,
+                    float* d_scale, int dtype, hipStream_t s);
+// out = y * scale[b] + S ;  S += out (skipped when d_S_out == nullptr)
+int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, void* d_S, int ldS, void* d_out,
+                    int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s);
+
+struct PoolLayer {
+  void* w2 = nullptr;       // [ccat_pad32][bott] dtype : pooling.linear2.weight rows padded to a multiple of 32
+  int ccat = 0, ccat_p = 0, bott = 0;
+};
+// attentive statistics: pooled[b] = [mean(ccat_p) | std(ccat_p)] (f32)
+int launch_pool_stats(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh,
+                      const int32_t* d_row_off, int B, float* d_pooled, int dtype, hipStream_t s);
+
+struct TailLayer {          // folded bnpool . linear . bnembed, f32
+  float* wt = nullptr;      // [2*ccat_p][embed]
+  float* bias = nullptr;    // [embed]
+  int in_p = 0, embed = 0;
+};
+int launch_tail(const TailLayer& t, const float* d_pooled, int B, float* d_emb, hipStream_t s);
+int launch_l2norm(float* d_x, int64_t n, int dim, hipStream_t s);
+
+// dtype -> f32 copy of a strided [R][C] activation (debug taps)
+int launch_to_f32(const void* d_x, int ldx, int64_t R, int C, float* d_out, int dtype, hipStream_t s);
+
+}  // namespace sugar

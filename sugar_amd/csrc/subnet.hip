@@ -1,0 +1,436 @@
+// Host side of libsugar_amd: packed subnets, workspace planning, the forward schedule and the C-ABI.
+//
+// The schedule is DynamicTDNN.forward (sugar/models/dynamictdnn.py:645-666) on packed channels-last rows:
+//   layer1 -> [first_conv -> 7 Res2 steps -> last_conv -> SE scale -> (scale, +S, S+=)] x depth
+//          -> catconv+ReLU -> pooling.linear1+tanh -> fused linear2/softmax/statistics -> folded tail.
+// torch.cat (:662) never materialises: every block writes its output straight into its column slice of the
+// catconv input; the Res2 split/cat (:291,302) are column offsets into two [R][mid] buffers.
+#include <math.h>
+#include <stdarg.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace sugar {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fbank_init();
+
+struct Block {
+  ConvLayer first, res[SUGAR_RES2_SCALE - 1], last;
+  SELayer se;
+  int w = 0, wp = 0, midp = 0, kernel = 1;
+};
+
+}  // namespace sugar
+
+struct SugarSubnet {
+  int dtype = SUGAR_BF16, device = 0;
+  int in_feats = 80, embed = 192, depth = 0, c0 = 0, c0p = 0, ccat = 0, ccatp = 0, bott = 128, midp_max = 0;
+  sugar::ConvLayer layer1, catconv, pool1;
+  sugar::Block blocks[SUGAR_MAX_DEPTH];
+  sugar::PoolLayer pool;
+  sugar::TailLayer tail;
+};
+
+namespace sugar {
+
+static int upload(float** dst, const std::vector<float>& v) {
+  SUGAR_HIP(hipMalloc(dst, v.size() * sizeof(float)));
+  SUGAR_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return SUGAR_OK;
+}
+
+static bool bn_ok(const SugarBN& b) { return b.weight && b.bias && b.running_mean && b.running_var; }
+
+static void destroy(SugarSubnet* n) {
+  free_conv(&n->layer1);
+  free_conv(&n->catconv);
+  free_conv(&n->pool1);
+  for (int i = 0; i < SUGAR_MAX_DEPTH; ++i) {
+    Block& b = n->blocks[i];
+    free_conv(&b.first);
+    free_conv(&b.last);
+    for (auto& r : b.res) free_conv(&r);
+    if (b.se.w1t) (void)hipFree(b.se.w1t);
+    if (b.se.b1) (void)hipFree(b.se.b1);
+    if (b.se.w2t) (void)hipFree(b.se.w2t);
+    if (b.se.b2) (void)hipFree(b.se.b2);
+  }
+  if (n->pool.w2) (void)hipFree(n->pool.w2);
+  if (n->tail.wt) (void)hipFree(n->tail.wt);
+  if (n->tail.bias) (void)hipFree(n->tail.bias);
+  delete n;
+}
+
+static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
+  const int E = dtype == SUGAR_F32 ? 4 : 8;
+  n->dtype = dtype;
+  n->in_feats = d->in_feats;
+  n->embed = d->embed_dim;
+  n->depth = d->depth;
+  n->c0 = d->c0;
+  n->c0p = (int)round_up(d->c0, 8);
+  n->ccat = d->ccat;
+  n->ccatp = (int)round_up(d->ccat, 8);
+  n->bott = d->bottleneck;
+  int rc;
+
+  // layer1: (in_feats, C0, K0), dilation 1                                         dynamictdnn.py:628
+  if ((rc = pack_conv(&n->layer1, d->layer1_w, &d->layer1_bn, d->c0, d->in_feats, d->k0, 1, EPI_RELU, n->c0p, nullptr,
+                      d->in_feats, nullptr, dtype)))
+    return rc;
+
+  for (int i = 0; i < d->depth; ++i) {
+    const SugarBlock& sb = d->blocks[i];
+    Block& b = n->blocks[i];
+    SUGAR_CHECK_ARG(sb.mid_channels > 0 && sb.mid_channels % SUGAR_RES2_SCALE == 0,
+                    "block %d: mid_channels %d must be a positive multiple of 8", i, sb.mid_channels);
+    SUGAR_CHECK_ARG(sb.first_w && sb.last_w && bn_ok(sb.first_bn) && bn_ok(sb.last_bn) && sb.se_reduce_w &&
+                        sb.se_reduce_b && sb.se_expand_w && sb.se_expand_b,
+                    "block %d: null tensor", i);
+    b.kernel = sb.kernel;
+    b.w = sb.mid_channels / SUGAR_RES2_SCALE;
+    b.wp = (int)round_up(b.w, 8);
+    b.midp = b.wp * SUGAR_RES2_SCALE;
+    if (b.midp > n->midp_max) n->midp_max = b.midp;
+    const int dil = i + 2;                                                         // dynamictdnn.py:629-632
+    std::vector<int> midmap(sb.mid_channels);
+    for (int g = 0; g < SUGAR_RES2_SCALE; ++g)
+      for (int j = 0; j < b.w; ++j) midmap[g * b.w + j] = g * b.wp + j;
+    if ((rc = pack_conv(&b.first, sb.first_w, &sb.first_bn, sb.mid_channels, d->c0, 1, 1, EPI_RELU, b.midp,
+                        midmap.data(), n->c0p, nullptr, dtype)))
+      return rc;
+    for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {
+      SUGAR_CHECK_ARG(sb.res_w[j] && bn_ok(sb.res_bn[j]), "block %d res2 conv %d: null tensor", i, j);
+      if ((rc = pack_conv(&b.res[j], sb.res_w[j], &sb.res_bn[j], b.w, b.w, sb.kernel, dil, EPI_RELU, b.wp, nullptr,
+                          b.wp, nullptr, dtype)))
+        return rc;
+    }
+    if ((rc = pack_conv(&b.last, sb.last_w, &sb.last_bn, d->c0, sb.mid_channels, 1, 1, EPI_RELU, n->c0p, nullptr,
+                        b.midp, midmap.data(), dtype)))
+      return rc;
+    // SE: reduce [hid][c0], expand [c0][hid]  -> transposed, channel-padded             dynamictdnn.py:88-89
+    const int hid = d->c0 / 4;
+    SUGAR_CHECK_ARG(hid > 0, "block %d: c0 %d too small for SE reduction 4", i, d->c0);
+    b.se.c = d->c0;
+    b.se.c_p = n->c0p;
+    b.se.hid = hid;
+    std::vector<float> w1t((size_t)n->c0p * hid, 0.f), b1(hid), w2t((size_t)hid * n->c0p, 0.f), b2(n->c0p, 0.f);
+    for (int j = 0; j < hid; ++j) {
+      b1[j] = sb.se_reduce_b[j];
+      for (int c = 0; c < d->c0; ++c) {
+        w1t[(size_t)c * hid + j] = sb.se_reduce_w[(size_t)j * d->c0 + c];
+        w2t[(size_t)j * n->c0p + c] = sb.se_expand_w[(size_t)c * hid + j];
+      }
+    }
+    for (int c = 0; c < d->c0; ++c) b2[c] = sb.se_expand_b[c];
+    if ((rc = upload(&b.se.w1t, w1t)) || (rc = upload(&b.se.b1, b1)) || (rc = upload(&b.se.w2t, w2t)) ||
+        (rc = upload(&b.se.b2, b2)))
+      return rc;
+  }
+
+  // catconv: input = cat of block outputs, each block padded to c0p                  dynamictdnn.py:633,662-663
+  {
+    std::vector<int> catmap((size_t)d->depth * d->c0);
+    for (int blk = 0; blk < d->depth; ++blk)
+      for (int j = 0; j < d->c0; ++j) catmap[(size_t)blk * d->c0 + j] = blk * n->c0p + j;
+    if ((rc = pack_conv(&n->catconv, d->catconv_w, nullptr, d->ccat, d->depth * d->c0, 1, 1, EPI_RELU, n->ccatp,
+                        nullptr, d->depth * n->c0p, catmap.data(), dtype)))
+      return rc;
+  }
+  // pooling.linear1 (+tanh) as a conv; pooling.linear2 as the fused kernel's B operand  dynamictdnn.py:498-499
+  if ((rc = pack_conv(&n->pool1, d->pool1_w, nullptr, d->bottleneck, d->ccat, 1, 1, EPI_TANH, d->bottleneck, nullptr,
+                      n->ccatp, nullptr, dtype)))
+    return rc;
+  {
+    const int rows = (int)round_up(n->ccatp, 128);
+    const size_t cnt = (size_t)rows * d->bottleneck;
+    const size_t esz = dtype == SUGAR_F32 ? 4 : 2;
+    std::vector<unsigned char> host(cnt * esz, 0);
+    for (int c = 0; c < d->ccat; ++c)
+      for (int k = 0; k < d->bottleneck; ++k) {
+        const float v = d->pool2_w[(size_t)c * d->bottleneck + k];
+        if (dtype == SUGAR_F32) ((float*)host.data())[(size_t)c * d->bottleneck + k] = v;
+        else ((uint16_t*)host.data())[(size_t)c * d->bottleneck + k] = host_f32_to_bf16(v);
+      }
+    SUGAR_HIP(hipMalloc(&n->pool.w2, cnt * esz));
+    SUGAR_HIP(hipMemcpy(n->pool.w2, host.data(), cnt * esz, hipMemcpyHostToDevice));
+    n->pool.ccat = d->ccat;
+    n->pool.ccat_p = n->ccatp;
+    n->pool.bott = d->bottleneck;
+  }
+  // tail: bnembed(linear(bnpool(p))) = W' p + b'                                      dynamictdnn.py:664-665
+  {
+    const int in = 2 * d->ccat, inp = 2 * n->ccatp, E_ = d->embed_dim;
+    std::vector<float> wt((size_t)inp * E_, 0.f), bias(E_);
+    std::vector<double> sp(in), tp(in);
+    for (int i = 0; i < in; ++i) {
+      sp[i] = (double)d->bnpool.weight[i] / sqrt((double)d->bnpool.running_var[i] + 1e-5);
+      tp[i] = (double)d->bnpool.bias[i] - (double)d->bnpool.running_mean[i] * sp[i];
+    }
+    for (int o = 0; o < E_; ++o) {
+      const double se = (double)d->bnembed.weight[o] / sqrt((double)d->bnembed.running_var[o] + 1e-5);
+      const double te = (double)d->bnembed.bias[o] - (double)d->bnembed.running_mean[o] * se;
+      double acc = d->linear_b[o];
+      for (int i = 0; i < in; ++i) {
+        const double wv = d->linear_w[(size_t)o * in + i];
+        acc += wv * tp[i];
+        const int pi = i < d->ccat ? i : n->ccatp + (i - d->ccat);
+        wt[(size_t)pi * E_ + o] = (float)(se * wv * sp[i]);
+      }
+      bias[o] = (float)(se * acc + te);
+    }
+    if ((rc = upload(&n->tail.wt, wt)) || (rc = upload(&n->tail.bias, bias))) return rc;
+    n->tail.in_p = inp;
+    n->tail.embed = E_;
+  }
+  (void)E;
+  return fbank_init();
+}
+
+// ---------------------------------------------------------------------------------- workspace
+struct Workspace {
+  int2* rowseg;
+  float* logmel;
+  void *feats, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
+  float *sescale, *pooled;
+  int64_t bytes;
+};
+
+static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
+  const int64_t esz = n->dtype == SUGAR_F32 ? 4 : 2;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    void* p = base ? (void*)((char*)base + off) : nullptr;
+    off += round_up(bytes, 256);
+    return p;
+  };
+  Workspace w;
+  w.rowseg = (int2*)take(R * (int64_t)sizeof(int2));
+  w.logmel = (float*)take(R * SUGAR_N_MELS * 4);
+  w.feats = take(R * SUGAR_N_MELS * esz);
+  w.S = take(R * n->c0p * esz);
+  w.cat = take(R * (int64_t)n->depth * n->c0p * esz);
+  w.mid1 = take(R * n->midp_max * esz);
+  w.mid2 = take(R * n->midp_max * esz);
+  w.ybuf = take(R * n->c0p * esz);
+  w.hbuf = take(R * n->ccatp * esz);
+  w.abuf = take(R * n->bott * esz);
+  w.sescale = (float*)take((int64_t)B * n->c0p * 4);
+  w.pooled = (float*)take((int64_t)B * 2 * n->ccatp * 4);
+  w.bytes = off;
+  return w;
+}
+
+// ---------------------------------------------------------------------------------- forward
+static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* row_off, int B, int64_t R, int t_max,
+                        const Workspace& w, float* d_emb, int normalize, int tap, float* tap_out, hipStream_t s) {
+  const int dt = n->dtype;
+  const int64_t esz = dt == SUGAR_F32 ? 4 : 2;
+  int rc;
+  auto col = [&](void* p, int64_t c) { return (void*)((char*)p + c * esz); };
+  auto tapcopy = [&](int id, const void* p, int ld, int C) -> int {
+    if (tap != id || !tap_out) return SUGAR_OK;
+    return launch_to_f32(p, ld, R, C, tap_out, dt, s);
+  };
+  if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc;
+
+  ConvIO io;
+  io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
+  if ((rc = launch_conv(n->layer1, io, w.rowseg, R, dt, s))) return rc;
+  if ((rc = tapcopy(0, w.S, n->c0p, n->c0p))) return rc;
+
+  const int ldcat = n->depth * n->c0p;
+  for (int i = 0; i < n->depth; ++i) {
+    const Block& b = n->blocks[i];
+    // block input: layer1 output (still == S) for block 0, else the previous block's slice of the cat buffer
+    const void* xin = i == 0 ? w.S : col(w.cat, (int64_t)(i - 1) * n->c0p);
+    const int ldin = i == 0 ? n->c0p : ldcat;
+    ConvIO f;
+    f.x = xin; f.ldx = ldin; f.y = w.mid1; f.ldy = b.midp;
+    f.y2 = w.mid2; f.ldy2 = b.midp; f.y2_from = (SUGAR_RES2_SCALE - 1) * b.wp;   // 8th split passes through (:300-301)
+    if ((rc = launch_conv(b.first, f, w.rowseg, R, dt, s))) return rc;
+    if ((rc = tapcopy(1 + 4 * i, w.mid1, b.midp, b.midp))) return rc;
+    for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {                              // dynamictdnn.py:294-299
+      ConvIO r;
+      r.x = col(w.mid1, (int64_t)j * b.wp); r.ldx = b.midp;
+      if (j > 0) { r.x2 = col(w.mid2, (int64_t)(j - 1) * b.wp); r.ldx2 = b.midp; }
+      r.y = col(w.mid2, (int64_t)j * b.wp); r.ldy = b.midp;
+      if ((rc = launch_conv(b.res[j], r, w.rowseg, R, dt, s))) return rc;
+    }
+    if ((rc = tapcopy(2 + 4 * i, w.mid2, b.midp, b.midp))) return rc;
+    ConvIO l;
+    l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
+    if ((rc = launch_conv(b.last, l, w.rowseg, R, dt, s))) return rc;
+    if ((rc = tapcopy(3 + 4 * i, w.ybuf, n->c0p, n->c0p))) return rc;
+    if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, w.sescale, dt, s))) return rc;
+    void* out = col(w.cat, (int64_t)i * n->c0p);
+    if ((rc = launch_se_apply(w.ybuf, n->c0p, w.sescale, n->c0p, w.S, n->c0p, out, ldcat, i + 1 < n->depth, row_off, B,
+                              t_max, dt, s)))
+      return rc;
+    if ((rc = tapcopy(4 + 4 * i, out, ldcat, n->c0p))) return rc;
+  }
+  ConvIO c;
+  c.x = w.cat; c.ldx = ldcat; c.y = w.hbuf; c.ldy = n->ccatp;
+  if ((rc = launch_conv(n->catconv, c, w.rowseg, R, dt, s))) return rc;
+  if ((rc = tapcopy(100, w.hbuf, n->ccatp, n->ccatp))) return rc;
+  ConvIO p1;
+  p1.x = w.hbuf; p1.ldx = n->ccatp; p1.y = w.abuf; p1.ldy = n->bott;
+  if ((rc = launch_conv(n->pool1, p1, w.rowseg, R, dt, s))) return rc;
+  if ((rc = tapcopy(102, w.abuf, n->bott, n->bott))) return rc;
+  if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, w.pooled, dt, s))) return rc;
+  if (tap == 101 && tap_out)
+    SUGAR_HIP(hipMemcpyAsync(tap_out, w.pooled, (size_t)B * 2 * n->ccatp * 4, hipMemcpyDeviceToDevice, s));
+  if ((rc = launch_tail(n->tail, w.pooled, B, d_emb, s))) return rc;
+  if (normalize && (rc = launch_l2norm(d_emb, B, n->embed, s))) return rc;
+  return SUGAR_OK;
+}
+
+static int check_fwd_args(const SugarSubnet* n, const void* in, const int32_t* row_off, int B, int64_t R, int t_max,
+                          void* ws, int64_t ws_bytes, float* emb) {
+  SUGAR_CHECK_ARG(n && in && row_off && ws && emb, "forward: null pointer");
+  SUGAR_CHECK_ARG(B > 0 && B <= 65535, "forward: batch %d out of range (1..65535)", B);
+  SUGAR_CHECK_ARG(R >= B && R < (1ll << 27), "forward: total frames %lld out of range", (long long)R);
+  SUGAR_CHECK_ARG(t_max > 0 && t_max <= R, "forward: t_max %d inconsistent with R %lld", t_max, (long long)R);
+  SUGAR_CHECK_ARG(((uintptr_t)ws & 255) == 0, "forward: workspace must be 256-byte aligned");
+  const int64_t need = plan(n, B, R, nullptr).bytes;
+  if (ws_bytes < need) {
+    set_error("forward: workspace %lld bytes < required %lld", (long long)ws_bytes, (long long)need);
+    return SUGAR_ENOMEM;
+  }
+  return SUGAR_OK;
+}
+
+}  // namespace sugar
+
+using namespace sugar;
+
+extern "C" {
+
+const char* sugar_last_error(void) { return g_err; }
+const char* sugar_version(void) { return "sugar_amd 0.1 (gfx950)"; }
+
+int sugar_subnet_create(const SugarSubnetDesc* d, int dtype, int device, SugarSubnet** out) {
+  SUGAR_CHECK_ARG(d && out, "subnet_create: null pointer");
+  SUGAR_CHECK_ARG(dtype == SUGAR_F32 || dtype == SUGAR_BF16, "subnet_create: bad dtype %d", dtype);
+  SUGAR_CHECK_ARG(d->depth >= 1 && d->depth <= SUGAR_MAX_DEPTH, "subnet_create: depth %d out of range", d->depth);
+  SUGAR_CHECK_ARG(d->in_feats == SUGAR_N_MELS, "subnet_create: in_feats %d (only 80 supported)", d->in_feats);
+  SUGAR_CHECK_ARG(d->c0 > 0 && d->ccat > 0 && d->embed_dim > 0 && d->bottleneck == 128,
+                  "subnet_create: bad dims c0 %d ccat %d embed %d bottleneck %d", d->c0, d->ccat, d->embed_dim,
+                  d->bottleneck);
+  SUGAR_CHECK_ARG(d->layer1_w && bn_ok(d->layer1_bn) && d->catconv_w && d->pool1_w && d->pool2_w && bn_ok(d->bnpool) &&
+                      d->linear_w && d->linear_b && bn_ok(d->bnembed),
+                  "subnet_create: null tensor");
+  SUGAR_HIP(hipSetDevice(device));
+  SugarSubnet* n = new SugarSubnet();
+  n->device = device;
+  const int rc = create(d, dtype, n);
+  if (rc) {
+    destroy(n);
+    return rc;
+  }
+  SUGAR_HIP(hipDeviceSynchronize());
+  *out = n;
+  return SUGAR_OK;
+}
+
+int sugar_subnet_destroy(SugarSubnet* net) {
+  if (net) destroy(net);
+  return SUGAR_OK;
+}
+
+int64_t sugar_workspace_bytes(const SugarSubnet* net, int B, int64_t R) {
+  if (!net || B <= 0 || R <= 0) {
+    set_error("workspace_bytes: bad arguments");
+    return SUGAR_EINVAL;
+  }
+  return plan(net, B, R, nullptr).bytes;
+}
+
+int sugar_fbank_fwd(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
+                    const int32_t* d_row_off, int B, int t_max, float* d_logmel, void* d_feats, int dtype,
+                    void* stream) {
+  return launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, d_logmel, d_feats, dtype, (hipStream_t)stream);
+}
+
+int sugar_tdnn_fwd(const SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R, int t_max,
+                   void* d_workspace, int64_t workspace_bytes, float* d_emb, int normalize, void* stream) {
+  int rc = check_fwd_args(net, d_feats, d_row_off, B, R, t_max, d_workspace, workspace_bytes, d_emb);
+  if (rc) return rc;
+  const Workspace w = plan(net, B, R, d_workspace);
+  return tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, (hipStream_t)stream);
+}
+
+int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
+                    const int32_t* d_row_off, int B, int64_t R, int t_max, void* d_workspace, int64_t workspace_bytes,
+                    float* d_emb, int normalize, void* stream) {
+  int rc = check_fwd_args(net, d_wav, d_row_off, B, R, t_max, d_workspace, workspace_bytes, d_emb);
+  if (rc) return rc;
+  SUGAR_CHECK_ARG(d_wav_off && d_wav_len, "embed_fwd: null pointer");
+  const Workspace w = plan(net, B, R, d_workspace);
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, w.logmel, w.feats, net->dtype, s))) return rc;
+  return tdnn_forward(net, w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
+}
+
+int sugar_tdnn_tap(const SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R, int t_max,
+                   void* d_workspace, int64_t workspace_bytes, int what, float* d_out, int64_t out_elems,
+                   float* d_emb, void* stream) {
+  int rc = check_fwd_args(net, d_feats, d_row_off, B, R, t_max, d_workspace, workspace_bytes, d_emb);
+  if (rc) return rc;
+  SUGAR_CHECK_ARG(d_out, "tap: null output");
+  int C = -1;
+  int64_t rows = R;
+  if (what == 0) C = net->c0p;
+  else if (what >= 1 && what <= 4 * net->depth) {
+    const int i = (what - 1) / 4, k = (what - 1) % 4;
+    C = (k == 0 || k == 1) ? net->blocks[i].midp : net->c0p;
+  } else if (what == 100) C = net->ccatp;
+  else if (what == 101) { C = 2 * net->ccatp; rows = B; }
+  else if (what == 102) C = net->bott;
+  SUGAR_CHECK_ARG(C > 0, "tap: unknown stage %d", what);
+  SUGAR_CHECK_ARG(out_elems >= rows * C, "tap: output holds %lld elements, stage needs %lld", (long long)out_elems,
+                  (long long)(rows * C));
+  const Workspace w = plan(net, B, R, d_workspace);
+  rc = tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, 0, what, d_out, (hipStream_t)stream);
+  return rc ? rc : C;
+}
+
+int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, int k, int dilation, int flags,
+                     const void* d_x, const void* d_x2, void* d_y, const int32_t* d_row_off, int B, int64_t R,
+                     int t_max, int dtype, void* stream) {
+  SUGAR_CHECK_ARG(dtype == SUGAR_F32 || dtype == SUGAR_BF16, "conv1d: bad dtype %d", dtype);
+  SUGAR_CHECK_ARG(h_w && d_x && d_y && d_row_off && B > 0 && R > 0 && t_max > 0, "conv1d: bad arguments");
+  SUGAR_CHECK_ARG(cin % 8 == 0 && cout % 8 == 0, "conv1d: this test entry needs channel counts that are multiples of 8");
+  ConvLayer L;
+  int rc = pack_conv(&L, h_w, (flags & EPI_AFFINE) ? h_bn : nullptr, cout, cin, k, dilation, flags, cout, nullptr, cin,
+                     nullptr, dtype);
+  if (rc) { free_conv(&L); return rc; }
+  int2* rowseg = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMalloc(&rowseg, R * sizeof(int2)) != hipSuccess) { free_conv(&L); set_error("conv1d: hipMalloc"); return SUGAR_EHIP; }
+  rc = launch_build_rowseg(d_row_off, B, t_max, rowseg, s);
+  if (!rc) {
+    ConvIO io;
+    io.x = d_x; io.ldx = cin; io.x2 = d_x2; io.ldx2 = cin; io.y = d_y; io.ldy = cout;
+    rc = launch_conv(L, io, rowseg, R, dtype, s);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(rowseg);
+  free_conv(&L);
+  return rc;
+}
+
+int sugar_l2norm(float* d_x, int64_t n, int dim, void* stream) { return launch_l2norm(d_x, n, dim, (hipStream_t)stream); }
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""
+Model API with the reference's names and call signatures (sugar/models/__init__.py:44-165):
+
+  SpeakerModel(modelarch, lossfunc=None, transform=None)   -- attributes ``__S__`` / ``__L__`` / ``__T__`` (:61-63)
+  WrappedModel(model).module                                -- DDP-shaped wrapper (:117-127)
+  WrappedModel.from_pretrained(...) -> (subnet, info)       -- same argument names and load order (:129-165)
+
+Differences, all forced by the environment or by the scope of this build:
+  * there is no network: ``supernet_filename`` / ``subnet_filename`` are LOCAL paths (``repo_id`` is a local
+    directory they are resolved against, or "" / None); file formats are the reference's
+    (``{'state_dict': {'module.__S__.*': ...}}`` and ``{'subnet': config, 'bn': {...}}``);
+  * ``precision`` ("bf16" default, "fp32") selects the MFMA path;
+  * ``forward`` also accepts a list of 1-D waveforms of different lengths (the reference runs those at batch 1);
+  * the loss head (``__L__``) is not on the inference path: ``label`` must be None.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .dynamictdnn import DynamicTDNN, TDNNSubnet, tdnn8m2g
+from .transforms import LogMelFbanks
+
+
+class SpeakerModel(nn.Module):
+    def __init__(self, modelarch, lossfunc=None, transform=None, keep_channel=False, features_last=False):
+        super().__init__()
+        if keep_channel or features_last:
+            raise ValueError("keep_channel / features_last are not used by the EfficientTDNN path")
+        self.__S__ = modelarch
+        self.__L__ = lossfunc
+        self.__T__ = transform
+        self.keep_channel = keep_channel
+        self.features_last = features_last
+
+    def __repr__(self):
+        n = sum(p.numel() for p in self.__S__.parameters())
+        return "Arch: %d" % n
+
+    def _subnet(self):
+        s = self.__S__
+        return s.active_subnet() if isinstance(s, DynamicTDNN) else s
+
+    def embed_ragged(self, wavs, normalize=False):
+        """List of 1-D float waveforms (any lengths > 256 samples) -> [len(wavs), 192]; one fused C-ABI call."""
+        if not isinstance(self.__T__, LogMelFbanks) or not isinstance(self.__S__, (TDNNSubnet, DynamicTDNN)):
+            raise _lib.SugarError("embed_ragged needs the fused LogMelFbanks + TDNN path")
+        sub = self._subnet()
+        dev = wavs[0].device
+        if dev.type != "cuda":
+            raise _lib.SugarError("sugar_amd runs on an MI355X only: waveforms must be CUDA tensors (no CPU fallback)")
+        plan = self.__T__.plan([int(w.numel()) for w in wavs], dev)
+        flat = torch.cat([w.reshape(-1).float() for w in wavs]) if len(wavs) > 1 else wavs[0].reshape(-1).float().contiguous()
+        return self._embed_flat(sub, flat, plan, normalize)
+
+    def _embed_flat(self, sub, flat, plan, normalize):
+        dev = flat.device
+        ws = sub.workspace(dev, plan.B, plan.R)
+        emb = torch.empty(plan.B, sub.out_embeds, dtype=torch.float32, device=dev)
+        rc = _lib.lib().sugar_embed_fwd(sub.handle(dev), flat.data_ptr(), plan.wav_off.data_ptr(),
+                                        plan.wav_len.data_ptr(), plan.row_off.data_ptr(), plan.B, plan.R, plan.t_max,
+                                        ws.data_ptr(), ws.numel(), emb.data_ptr(), int(normalize),
+                                        torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "sugar_embed_fwd")
+        return emb
+
+    def forward(self, batch, label=None, normalize=False):
+        """
+        batch: [B, L], [B, 1, L] or [B, U, L] waveforms (sugar/models/__init__.py:79-94), or pre-computed features
+        when transform is None, or a list of 1-D waveforms.  Returns embeddings [B*U, 192].
+        """
+        if label is not None:
+            raise ValueError("the loss head is outside the embedding-extraction path: label must be None")
+        if isinstance(batch, (list, tuple)):
+            return self.embed_ragged(list(batch), normalize)
+        sizes = list(batch.size())
+        if len(sizes) == 2 or (len(sizes) == 3 and sizes[1] != 1):
+            batch = batch.unsqueeze(1)
+            sizes = list(batch.size())
+        batch = batch.reshape([-1] + sizes[2:])
+        if self.__T__ is None:
+            emb = self.__S__(batch.squeeze(1) if batch.dim() == 4 else batch)
+            if normalize:
+                _lib.check(_lib.lib().sugar_l2norm(emb.data_ptr(), emb.shape[0], emb.shape[1],
+                                                   torch.cuda.current_stream(emb.device).cuda_stream), "sugar_l2norm")
+            return emb
+        if isinstance(self.__T__, LogMelFbanks) and isinstance(self.__S__, (TDNNSubnet, DynamicTDNN)) and batch.dim() == 2:
+            if not batch.is_cuda:
+                raise _lib.SugarError("sugar_amd runs on an MI355X only: waveforms must be CUDA tensors (no CPU fallback)")
+            B, L = batch.shape
+            plan = self.__T__.plan([L] * B, batch.device)
+            return self._embed_flat(self._subnet(), batch.float().contiguous().view(-1), plan, normalize)
+        feats = self.__T__(batch).squeeze(1)
+        return self.__S__(feats)
+
+
+class WrappedModel(nn.Module):
+    """sugar/models/__init__.py:117-165."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.module = model
+
+    def forward(self, x, label=None, normalize=False):
+        return self.module(x, label, normalize=normalize)
+
+    @classmethod
+    def from_pretrained(cls, repo_id="", supernet_filename="depth/depth.torchparams",
+                        subnet_filename="depth/depth.ecapa-tdnn.3.512.512.512.512.5.3.3.3.1536.bn.tar",
+                        feat_type="logmelfbank", feat_dim=80, model_type="tdnn8m2g", embed_dim=192,
+                        precision="bf16"):
+        def resolve(name):
+            path = name if (os.path.isabs(name) or not repo_id) else os.path.join(repo_id, name)
+            if not os.path.isfile(path):
+                raise FileNotFoundError(
+                    "%s: no network in this build -- pass local files (repo_id is treated as a local directory)" % path)
+            return path
+
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"{precision} not in {['bf16', 'fp32']}")
+        supernet_path = resolve(supernet_filename)
+        sup_state_dict = torch.load(supernet_path, map_location="cpu", weights_only=True)["state_dict"]
+        if feat_type == "logmelfbank":
+            transform = LogMelFbanks(n_mels=feat_dim)
+        else:
+            raise ValueError(f"{feat_type} not in {['logmelfbank']}")
+        if model_type == "tdnn8m2g":
+            modelarch = tdnn8m2g(in_feats=feat_dim, out_embeds=embed_dim)
+        else:
+            raise ValueError(f"{model_type} not in {['tdnn8m2g']}")
+        modelarch.precision = precision
+        model = cls(SpeakerModel(modelarch, transform=transform))
+        model.load_state_dict(sup_state_dict, strict=False)       # module.__L__.W etc. are unexpected keys, as upstream
+        if subnet_filename not in ["", None]:
+            subnet_bn_path = resolve(subnet_filename)
+            sub_state_dict = torch.load(subnet_bn_path, map_location="cpu", weights_only=True)
+            subnet_config = sub_state_dict["subnet"]
+            subnet = model.module.__S__.clone(subnet_config)
+            subnet.load_state_dict(sub_state_dict["bn"], strict=False)
+            subnet = cls(SpeakerModel(subnet, transform=transform))
+        else:
+            subnet = subnet_bn_path = sub_state_dict = None
+        info = {"supernet_file": supernet_path, "supernet": sup_state_dict, "supernet_model": model,
+                "subnet_file": subnet_bn_path, "subnet": sub_state_dict}
+        return subnet, info
+
+
+def checkpoint2backbone(state_dict):
+    """Strip ``module.__S__.`` from a checkpoint's state dict (sugar/models/__init__.py:168-198, without the file I/O)."""
+    return {k.replace("module.__S__.", ""): v for k, v in state_dict.items() if "__S__" in k}
+
+
+def bn_state_dict(model, removed_prefix=""):
+    """BN-only state dict of a subnet: the ``'bn'`` entry of a ``*.bn.tar`` file (sugar/utils/utility.py:9-23)."""
+    keys = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")
+    out = {}
+    for k, v in model.state_dict().items():
+        prefix, _, leaf = k.rpartition(".")
+        if leaf in keys and (prefix.endswith(".bn") or prefix.endswith("bnpool") or prefix.endswith("bnembed")):
+            out[k.replace(removed_prefix, "")] = v
+    return out
