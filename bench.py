@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""
+bench.py -- speaker embeddings/sec (3 s @ 16 kHz) of the MI355X-native EfficientTDNN extraction path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload base256|largest256] [--precision bf16|fp32]
+
+One step = one pass of the hot path (waveforms already resident in HBM -> fused fbank -> TDNN -> L2-normalised
+embeddings) over one batch of 256 synthetic 3 s utterances per GPU.  N > 1: launched by torch.distributed.run, one
+rank per GPU, utterance batches sharded across ranks (weak scaling, no data-path collective inside the network);
+the only exchange step is the all-gather of the [256, 192] embeddings of each step (RCCL over xGMI), issued
+asynchronously and completed inside the timed region.
+
+Rank 0 prints ONE JSON line (see the driver contract); it carries
+  roofline     : the dominant kernel = the catconv implicit-GEMM launch (49 % of the MACs): algorithmic FLOPs per
+                 launch / its average duration, measured live with hipEvents on the launch stream over the timed steps
+  cpu_baseline : the oracle (oracle/ref_cpu.py, a CPU restatement of the reference path) timed on the host cores
+                 on a bounded sample (8 x 3 s batches for ~10 s), rank 0 at N = 1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (config, per-GPU batch, samples)   BASELINE.json configs[1] / configs[2]
+    "base256": ("BASE", 256, 48000),
+    "largest256": ("LARGEST", 256, 48000),
+}
+PEAK = {"bf16": (2500.0, "dense bf16 MFMA peak, MI355X_MICROARCH.md chip table"),
+        "fp32": (157.3, "f32 matrix peak, MI355X_MICROARCH.md chip table")}
+
+
+def cpu_baseline(config, seconds=10.0):
+    """Oracle on the host cores: embeddings/s of 8 x 3 s batches (bounded sample of the same workload)."""
+    from oracle import ref_cpu
+    from sugar_amd import layout, synth
+    cores = min(os.cpu_count() or 1, 16)           # the GPU box gives one job a 16-CPU share
+    torch.set_num_threads(cores)
+    sd = synth.fill_state_dict(layout.supernet_shapes(), seed=0)
+    osd = ref_cpu.clone_state(sd, config)
+    wav = synth.waveforms(8, 48000, seed=100)
+    for _ in range(2):
+        ref_cpu.embed(osd, config[0], wav, norm=True)
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or time.perf_counter() - t0 < seconds:
+        ref_cpu.embed(osd, config[0], wav, norm=True)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(8 * n / dt, 2), "unit": "embeddings/s", "cores": cores, "kind": "port",
+            "sample": "%d forwards of 8 x 3 s (48000-sample) utterances, f32 oracle (torch CPU), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="base256", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print a per-stage hipEvent breakdown to stderr")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    import sugar_amd
+    from sugar_amd import _lib, layout, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg_name, B, L = WORKLOADS[args.workload]
+    config = getattr(layout, cfg_name)
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    sub = sup.clone(config).set_precision(args.precision)
+    model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+
+    # synthetic N(0,1) waveforms, resident in HBM before the timed region; each rank gets its own utterances
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    wav = torch.randn(B, L, device=dev, generator=g, dtype=torch.float32)
+    T = 1 + L // 160
+    R = B * T
+
+    gathered = [torch.empty(world * B, 192, device=dev) for _ in range(2)] if world > 1 else None
+
+    def step(i):
+        emb = model(wav, normalize=True)
+        if world > 1:
+            return dist.all_gather_into_tensor(gathered[i & 1], emb, async_op=True)
+        return None
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        h = step(i)
+        if h is not None:
+            h.wait()
+    _lib.profile_enable(1 << _lib.STAGE_CATCONV)       # 2 hipEvents per step around the dominant kernel
+    sync_all()
+    t0 = time.perf_counter()
+    pending = None
+    for i in range(args.steps):
+        h = step(i)
+        if pending is not None:
+            pending.wait()
+        pending = h
+    if pending is not None:
+        pending.wait()
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stages = None
+    if args.stages and rank == 0:
+        _lib.profile_enable((1 << _lib.STAGE_COUNT) - 1)
+        for i in range(5):
+            model(wav, normalize=True)
+        torch.cuda.synchronize(dev)
+        stages = {k: round(ms / 5, 4) for k, (n, ms) in _lib.profile_read().items()}
+        _lib.profile_enable(0)
+        print("per-stage ms/step (hipEvents, 5 steps): " + json.dumps(stages), file=sys.stderr)
+
+    if rank == 0:
+        n_cat, ms_cat = prof.get("catconv", (0, 0.0))
+        depth, ch, _, ccat = config
+        flops_launch = 2.0 * (depth * ch[0]) * ccat * R               # algorithmic: 2 * K * N * frames
+        peak, peak_src = PEAK[args.precision]
+        achieved = flops_launch / (ms_cat / n_cat * 1e-3) / 1e12 if n_cat else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_catconv.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("%s_%s" % (args.workload, args.precision))
+        out = {
+            "metric": "speaker embeddings/sec (3 s @16 kHz)",
+            "value": round(world * B * args.steps / dt, 1),
+            "unit": "embeddings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%s: EfficientTDNN subnet %s, %d x 3 s (48000-sample) utterances per GPU, "
+                                   "waveform -> fbank -> TDNN -> L2-normalised 192-d embedding"
+                                   % (args.workload, layout.config_name(config), B),
+                       "per_gpu_batch": B, "global_batch": world * B, "frames_per_utt": T,
+                       "parallelism": "utterance-sharded x%d, all-gather of embeddings" % world,
+                       "weights": "deterministic synthetic (sugar_amd/synth.py)"},
+            "roofline": {"kernel": "conv_gemm_kernel<%s,128,128> catconv launch [%d frames x K %d -> %d]"
+                                   % (args.precision, R, depth * ch[0], ccat),
+                         "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None,
+                         "traffic": traffic, "launches_timed": n_cat,
+                         "avg_launch_ms": round(ms_cat / n_cat, 4) if n_cat else None,
+                         "flops_per_launch": flops_launch, "peak_source": peak_src},
+        }
+        if stages:
+            out["stages_ms"] = stages
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(config)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

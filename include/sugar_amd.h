@@ -168,6 +168,30 @@ int sugar_cosine_trials(const float* d_vec, int dim, const int32_t* d_seg_off, i
                         const int32_t* d_enroll, const int32_t* d_test, int64_t n_trials,
                         float* d_scores, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Live per-stage timing (bench.py's roofline figures).  No reference counterpart; the reference times whole
+ * forwards with torch.cuda.synchronize (sugar/metrics.py:389-404).
+ * sugar_profile_enable(mask): bit i set => every launch group of stage i inside sugar_embed_fwd / sugar_tdnn_fwd is
+ * bracketed by a hipEvent pair recorded on the call's own stream; clears earlier records.  mask 0 = off (default).
+ * sugar_profile_read(stage, &count, &total_ms): synchronises those events and returns how many brackets were
+ * recorded and the sum of their elapsed times. */
+#define SUGAR_STAGE_FBANK 0
+#define SUGAR_STAGE_LAYER1 1
+#define SUGAR_STAGE_FIRST 2
+#define SUGAR_STAGE_RES2 3
+#define SUGAR_STAGE_LAST 4
+#define SUGAR_STAGE_SE_SCALE 5
+#define SUGAR_STAGE_SE_APPLY 6
+#define SUGAR_STAGE_CATCONV 7
+#define SUGAR_STAGE_POOL1 8
+#define SUGAR_STAGE_POOL_STATS 9
+#define SUGAR_STAGE_TAIL 10
+#define SUGAR_STAGE_ROWSEG 11
+#define SUGAR_STAGE_COUNT 12
+int sugar_profile_enable(unsigned mask);
+int sugar_profile_read(int stage, int* count, double* total_ms);
+const char* sugar_profile_stage_name(int stage);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,9 @@ SYMBOLS = {
     "sugar_tdnn_tap": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "sugar_conv1d_fwd": (_i, [_fp, C.POINTER(SugarBN), _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "sugar_l2norm": (_i, [_vp, _i64, _i, _vp]),
+    "sugar_profile_enable": (_i, [C.c_uint]),
+    "sugar_profile_read": (_i, [_i, C.POINTER(_i), C.POINTER(C.c_double)]),
+    "sugar_profile_stage_name": (C.c_char_p, [_i]),
     "sugar_cosine_trials": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
 }
 
@@ -86,6 +89,25 @@ def check(rc, what=""):
             raise ValueError("%s: %s" % (what or "sugar_amd", msg))
         raise SugarError("%s: %s (code %d)" % (what or "sugar_amd", msg, rc))
     return rc
+
+
+STAGE_COUNT = 12
+STAGE_CATCONV = 7
+
+
+def profile_enable(mask):
+    check(lib().sugar_profile_enable(mask), "sugar_profile_enable")
+
+
+def profile_read():
+    """{stage name: (brackets recorded, total ms)} for every stage with at least one record."""
+    out = {}
+    for st in range(STAGE_COUNT):
+        n, ms = C.c_int(0), C.c_double(0.0)
+        check(lib().sugar_profile_read(st, C.byref(n), C.byref(ms)), "sugar_profile_read")
+        if n.value:
+            out[lib().sugar_profile_stage_name(st).decode()] = (n.value, ms.value)
+    return out
 
 
 def fptr(t):

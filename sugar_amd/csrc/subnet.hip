@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -24,6 +25,41 @@ void set_error(const char* fmt, ...) {
 }
 
 int fbank_init();
+
+// ---- optional hipEvent bracketing of the launches of one stage (bench.py's live per-kernel timing) ----
+static const char* kStageNames[SUGAR_STAGE_COUNT] = {"fbank_dft+instnorm", "layer1", "first_conv", "res2_steps", "last_conv",
+                                                     "se_scale", "se_apply", "catconv", "pool_linear1", "pool_stats",
+                                                     "tail+l2norm", "rowseg"};
+struct ProfRec { int stage; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static unsigned g_prof_mask = 0;
+static std::vector<ProfRec> g_prof_recs;     // recorded pairs
+static std::vector<hipEvent_t> g_prof_pool;  // reusable events
+
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct Prof {
+  hipStream_t s; int idx = -1;
+  Prof(int stage, hipStream_t s_) : s(s_) {
+    if (!(g_prof_mask >> stage & 1u)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{stage, prof_event(), prof_event()};
+    if (!r.a || !r.b) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof_recs.push_back(r);
+    idx = (int)g_prof_recs.size() - 1;
+  }
+  ~Prof() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof_recs[idx].b, s);
+  }
+};
 
 struct Block {
   ConvLayer first, res[SUGAR_RES2_SCALE - 1], last;
@@ -243,11 +279,11 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     if (tap != id || !tap_out) return SUGAR_OK;
     return launch_to_f32(p, ld, R, C, tap_out, dt, s);
   };
-  if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc;
+  { Prof p(SUGAR_STAGE_ROWSEG, s); if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc; }
 
   ConvIO io;
   io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
-  if ((rc = launch_conv(n->layer1, io, w.rowseg, R, dt, s))) return rc;
+  { Prof p(SUGAR_STAGE_LAYER1, s); if ((rc = launch_conv(n->layer1, io, w.rowseg, R, dt, s))) return rc; }
   if ((rc = tapcopy(0, w.S, n->c0p, n->c0p))) return rc;
 
   const int ldcat = n->depth * n->c0p;
@@ -259,8 +295,10 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     ConvIO f;
     f.x = xin; f.ldx = ldin; f.y = w.mid1; f.ldy = b.midp;
     f.y2 = w.mid2; f.ldy2 = b.midp; f.y2_from = (SUGAR_RES2_SCALE - 1) * b.wp;   // 8th split passes through (:300-301)
-    if ((rc = launch_conv(b.first, f, w.rowseg, R, dt, s))) return rc;
+    { Prof p(SUGAR_STAGE_FIRST, s); if ((rc = launch_conv(b.first, f, w.rowseg, R, dt, s))) return rc; }
     if ((rc = tapcopy(1 + 4 * i, w.mid1, b.midp, b.midp))) return rc;
+    {
+    Prof p(SUGAR_STAGE_RES2, s);
     for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {                              // dynamictdnn.py:294-299
       ConvIO r;
       r.x = col(w.mid1, (int64_t)j * b.wp); r.ldx = b.midp;
@@ -268,29 +306,34 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
       r.y = col(w.mid2, (int64_t)j * b.wp); r.ldy = b.midp;
       if ((rc = launch_conv(b.res[j], r, w.rowseg, R, dt, s))) return rc;
     }
+    }
     if ((rc = tapcopy(2 + 4 * i, w.mid2, b.midp, b.midp))) return rc;
     ConvIO l;
     l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
-    if ((rc = launch_conv(b.last, l, w.rowseg, R, dt, s))) return rc;
+    { Prof p(SUGAR_STAGE_LAST, s); if ((rc = launch_conv(b.last, l, w.rowseg, R, dt, s))) return rc; }
     if ((rc = tapcopy(3 + 4 * i, w.ybuf, n->c0p, n->c0p))) return rc;
-    if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, w.sescale, dt, s))) return rc;
+    { Prof p(SUGAR_STAGE_SE_SCALE, s); if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, w.sescale, dt, s))) return rc; }
     void* out = col(w.cat, (int64_t)i * n->c0p);
-    if ((rc = launch_se_apply(w.ybuf, n->c0p, w.sescale, n->c0p, w.S, n->c0p, out, ldcat, i + 1 < n->depth, row_off, B,
-                              t_max, dt, s)))
-      return rc;
+    {
+      Prof p(SUGAR_STAGE_SE_APPLY, s);
+      if ((rc = launch_se_apply(w.ybuf, n->c0p, w.sescale, n->c0p, w.S, n->c0p, out, ldcat, i + 1 < n->depth, row_off, B,
+                                t_max, dt, s)))
+        return rc;
+    }
     if ((rc = tapcopy(4 + 4 * i, out, ldcat, n->c0p))) return rc;
   }
   ConvIO c;
   c.x = w.cat; c.ldx = ldcat; c.y = w.hbuf; c.ldy = n->ccatp;
-  if ((rc = launch_conv(n->catconv, c, w.rowseg, R, dt, s))) return rc;
+  { Prof p(SUGAR_STAGE_CATCONV, s); if ((rc = launch_conv(n->catconv, c, w.rowseg, R, dt, s))) return rc; }
   if ((rc = tapcopy(100, w.hbuf, n->ccatp, n->ccatp))) return rc;
   ConvIO p1;
   p1.x = w.hbuf; p1.ldx = n->ccatp; p1.y = w.abuf; p1.ldy = n->bott;
-  if ((rc = launch_conv(n->pool1, p1, w.rowseg, R, dt, s))) return rc;
+  { Prof p(SUGAR_STAGE_POOL1, s); if ((rc = launch_conv(n->pool1, p1, w.rowseg, R, dt, s))) return rc; }
   if ((rc = tapcopy(102, w.abuf, n->bott, n->bott))) return rc;
-  if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, w.pooled, dt, s))) return rc;
+  { Prof p(SUGAR_STAGE_POOL_STATS, s); if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, w.pooled, dt, s))) return rc; }
   if (tap == 101 && tap_out)
     SUGAR_HIP(hipMemcpyAsync(tap_out, w.pooled, (size_t)B * 2 * n->ccatp * 4, hipMemcpyDeviceToDevice, s));
+  Prof p(SUGAR_STAGE_TAIL, s);
   if ((rc = launch_tail(n->tail, w.pooled, B, d_emb, s))) return rc;
   if (normalize && (rc = launch_l2norm(d_emb, B, n->embed, s))) return rc;
   return SUGAR_OK;
@@ -379,7 +422,7 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
   SUGAR_CHECK_ARG(d_wav_off && d_wav_len, "embed_fwd: null pointer");
   const Workspace w = plan(net, B, R, d_workspace);
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, w.logmel, w.feats, net->dtype, s))) return rc;
+  { Prof p(SUGAR_STAGE_FBANK, s); if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, w.logmel, w.feats, net->dtype, s))) return rc; }
   return tdnn_forward(net, w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
 }
 
@@ -429,6 +472,36 @@ int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, i
   (void)hipFree(rowseg);
   free_conv(&L);
   return rc;
+}
+
+int sugar_profile_enable(unsigned mask) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  g_prof_recs.clear();
+  g_prof_mask = mask;
+  return SUGAR_OK;
+}
+
+int sugar_profile_read(int stage, int* count, double* total_ms) {
+  SUGAR_CHECK_ARG(stage >= 0 && stage < SUGAR_STAGE_COUNT && count && total_ms, "profile_read: bad arguments");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  double t = 0.0;
+  for (auto& r : g_prof_recs) {
+    if (r.stage != stage) continue;
+    SUGAR_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    SUGAR_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    t += ms;
+    ++n;
+  }
+  *count = n;
+  *total_ms = t;
+  return SUGAR_OK;
+}
+
+const char* sugar_profile_stage_name(int stage) {
+  return (stage >= 0 && stage < SUGAR_STAGE_COUNT) ? kStageNames[stage] : "";
 }
 
 int sugar_l2norm(float* d_x, int64_t n, int dim, void* stream) { return launch_l2norm(d_x, n, dim, (hipStream_t)stream); }

@@ -1,0 +1,56 @@
+"""CPU, world_size 2 over gloo: the multi-GPU exchange step (utterance shards + one all-gather of embeddings)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sugar_amd import synth
+from sugar_amd.vectors import gather_vectors, shard_indices
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_utts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lengths = synth.ragged_lengths(n_utts, seed=5).tolist()
+    mine = shard_indices(n_utts, rank, world, lengths)
+    # stand-in for the embeddings this rank computed: row u of the global table
+    table = synth.normal("dist/emb", (n_utts, 192), seed=5)
+    local = table[mine]
+    parts = gather_vectors(local)
+    full = torch.empty(n_utts, 192)
+    for r, part in enumerate(parts):
+        full[shard_indices(n_utts, r, world, lengths)] = part
+    q.put((rank, bool(torch.equal(full, table)), [p.shape[0] for p in parts]))
+    dist.destroy_process_group()
+
+
+def test_allgather_uneven_shards_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_utts = 37   # odd on purpose: shards of 19 and 18 rows
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_utts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, sizes in res:
+        assert ok, rank
+        assert sizes == [19, 18]
+
+
+def test_gather_without_process_group_is_identity():
+    x = torch.ones(3, 192)
+    assert gather_vectors(x)[0] is x

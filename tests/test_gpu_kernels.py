@@ -1,0 +1,216 @@
+"""GPU: each HIP kernel, called through the C-ABI, against the oracle on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sugar_amd
+from conftest import cfg_of
+from oracle import ref_cpu
+from sugar_amd import _lib, layout, synth
+from sugar_amd.transforms import BatchPlan
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _row_off(frames):
+    off = [0]
+    for t in frames:
+        off.append(off[-1] + t)
+    return off
+
+
+def _conv_case(dtype, cin, cout, k, dil, flags, frames, with_x2, seed):
+    """Run sugar_conv1d_fwd on packed channels-last rows and the oracle (F.conv1d per utterance) on the same data."""
+    tdt = torch.float32 if dtype == _lib.SUGAR_F32 else torch.bfloat16
+    R = sum(frames)
+    off = _row_off(frames)
+    x = synth.normal("conv/x", (R, cin), seed).to(tdt)
+    x2 = synth.normal("conv/x2", (R, cin), seed).to(tdt) if with_x2 else None
+    w = synth.uniform("conv/w", (cout, cin, k), -1.0, 1.0, seed) * (3.0 / (cin * k)) ** 0.5
+    bn = synth.fill_state_dict({"b.weight": (cout,), "b.bias": (cout,), "b.running_mean": (cout,), "b.running_var": (cout,)}, seed)
+    # oracle on the values the kernel actually sees (inputs / weights rounded to the compute dtype)
+    wq = w.to(tdt).float()
+    xin = x.float() + (x2.float() if with_x2 else 0)
+    if with_x2:
+        xin = xin.to(tdt).float()
+    outs = []
+    for b in range(len(frames)):
+        seg = xin[off[b]:off[b + 1]].t().unsqueeze(0)
+        y = F.conv1d(seg, wq, None, 1, ((k - 1) // 2) * dil, dil)
+        if flags & 1:
+            y = F.relu(y)
+        if flags & 2:
+            y = F.batch_norm(y, bn["b.running_mean"], bn["b.running_var"], bn["b.weight"], bn["b.bias"], False, 0.0, 1e-5)
+        if flags & 4:
+            y = torch.tanh(y)
+        outs.append(y[0].t())
+    want = torch.cat(outs)
+    xd = x.to(DEV)
+    x2d = x2.to(DEV) if with_x2 else None
+    yd = torch.full((R, cout), float("nan"), dtype=tdt, device=DEV)
+    rowd = torch.tensor(off, dtype=torch.int32, device=DEV)
+    cbn = _lib.SugarBN(*[_lib.fptr(bn["b." + n]) for n in ("weight", "bias", "running_mean", "running_var")])
+    wc = w.contiguous()
+    rc = _lib.lib().sugar_conv1d_fwd(_lib.fptr(wc), C.byref(cbn), cout, cin, k, dil, flags, xd.data_ptr(),
+                                     x2d.data_ptr() if with_x2 else None, yd.data_ptr(), rowd.data_ptr(), len(frames), R,
+                                     max(frames), dtype, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "sugar_conv1d_fwd")
+    torch.cuda.synchronize()
+    return yd.float().cpu(), want
+
+
+CONV_CASES = [
+    # cin, cout, k, dil, flags, frames, x2
+    (80, 512, 5, 1, 3, [63], False),                      # layer1 (K = 400 -> padded K tile)
+    (512, 512, 1, 1, 3, [301, 301], False),               # first/last 1x1
+    (64, 64, 3, 2, 3, [301, 17, 130], True),              # Res2 step, ragged utterances, addend
+    (64, 64, 5, 5, 3, [301, 63], True),                   # widest halo: k 5, dilation 5
+    (16, 16, 1, 3, 3, [63, 63], True),                    # narrow subnet width (padded to the 64-row tile)
+    (24, 24, 3, 4, 3, [40, 200], False),                  # width 22 padded to 24
+    (1536, 1536, 1, 1, 1, [150], False),                  # catconv: ReLU only
+    (1536, 128, 1, 1, 4, [129], False),                   # pooling.linear1 + tanh
+    (176, 48, 1, 1, 0, [5, 1, 300], False),               # odd sizes, no epilogue, 1-frame utterance
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "cin%d_cout%d_k%d_d%d_f%d" % c[:5])
+def test_conv_f32(case):
+    got, want = _conv_case(_lib.SUGAR_F32, *case[:6], with_x2=case[6], seed=1)
+    assert torch.isfinite(got).all()
+    assert _rel(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "cin%d_cout%d_k%d_d%d_f%d" % c[:5])
+def test_conv_bf16(case):
+    got, want = _conv_case(_lib.SUGAR_BF16, *case[:6], with_x2=case[6], seed=2)
+    assert torch.isfinite(got).all()
+    # inputs/weights are identical bf16 values on both sides; the only difference is the bf16 rounding of the output
+    assert _rel(got, want) < 6e-3
+
+
+def test_conv_rejects_bad_arguments():
+    x = torch.zeros(8, 12, device=DEV)
+    w = torch.zeros(8, 12, 1)
+    off = torch.tensor([0, 8], dtype=torch.int32, device=DEV)
+    rc = _lib.lib().sugar_conv1d_fwd(_lib.fptr(w), None, 8, 12, 1, 1, 0, x.data_ptr(), None, x.data_ptr(), off.data_ptr(),
+                                     1, 8, 8, _lib.SUGAR_F32, None)
+    assert rc == -1
+    rc = _lib.lib().sugar_conv1d_fwd(_lib.fptr(w), None, 8, 16, 4, 1, 0, x.data_ptr(), None, x.data_ptr(), off.data_ptr(),
+                                     1, 8, 8, _lib.SUGAR_F32, None)
+    assert rc == -1 and b"bad shape" in _lib.lib().sugar_last_error()
+
+
+# ------------------------------------------------------------------------------------------ front-end
+def test_fbank_cfg1_matches_oracle(golden):
+    wav = synth.waveforms(1, 10000, seed=0)
+    got = sugar_amd.LogMelFbanks()(wav.to(DEV)).cpu()
+    assert got.shape == (1, 1, 80, 63)
+    want = torch.from_numpy(golden["fbank/cfg1"])
+    assert (got[0, 0] - want).abs().max() < 2e-3
+    assert (got[0, 0] - ref_cpu.logmel_fbank(wav)[0, 0]).abs().max() < 2e-3
+
+
+def test_fbank_batch_and_ragged_match_oracle():
+    fb = sugar_amd.LogMelFbanks()
+    wav = synth.waveforms(5, 48000, seed=4)
+    got = fb(wav.to(DEV)).cpu()
+    want = ref_cpu.logmel_fbank(wav)
+    assert got.shape == want.shape == (5, 1, 80, 301)
+    assert (got - want).abs().max() < 2e-3
+    # ragged: lengths straddling the 64-frame tile and the 160-sample hop; each utterance normalised on its own frames
+    lens = [257, 10239, 10240, 10241, 48000, 20479, 66666]
+    wavs = synth.ragged_waveforms(lens, seed=9)
+    plan = BatchPlan(lens, DEV)
+    rows = fb.rows(torch.cat(wavs).to(DEV), plan).cpu()
+    off = plan.row_off.cpu().tolist()
+    for i, wv in enumerate(wavs):
+        want = ref_cpu.logmel_fbank(wv.unsqueeze(0))[0, 0].t()
+        assert rows[off[i]:off[i + 1]].shape == want.shape
+        assert (rows[off[i]:off[i + 1]] - want).abs().max() < 2e-3, lens[i]
+    # bf16 output is the rounded f32 output
+    rows16 = fb.rows(torch.cat(wavs).to(DEV), plan, torch.bfloat16).float().cpu()
+    assert (rows16 - rows).abs().max() < 0.04
+
+
+# ------------------------------------------------------------------------------------------ backbone stages
+def _unpack(act, name, dims, i=None):
+    """Internal padded channel layout -> reference channel order."""
+    if name in ("first", "res2"):
+        w, wp = dims["w"][i], dims["wp"][i]
+        idx = torch.tensor([g * wp + j for g in range(8) for j in range(w)])
+        return act[:, idx]
+    return act
+
+
+@pytest.mark.parametrize("name", ["smallest", "odd"])
+def test_stage_taps_match_reference_f32(name, golden, meta, supernet):
+    cfg = cfg_of(meta, name)
+    sub = supernet.clone(cfg).set_precision("fp32")
+    supernet.config = None
+    x = ref_cpu.logmel_fbank(synth.waveforms(1, 10000, seed=0)).squeeze(1)      # oracle features -> backbone only
+    feats = x[0].t().contiguous().to(DEV)
+    row_off = torch.tensor([0, 63], dtype=torch.int32, device=DEV)
+    dims = sub.packed_dims()
+    depth, ch, _, ccat = cfg
+    taps = [(0, "layer1", None)]
+    for i in range(depth):
+        taps += [(1 + 4 * i, "b%d.first" % i, i), (2 + 4 * i, "b%d.res2" % i, i), (3 + 4 * i, "b%d.last" % i, i),
+                 (4 + 4 * i, "b%d.out" % i, i)]
+    taps += [(100, "catconv", None)]
+    errs = {}
+    for what, key, i in taps:
+        act, _ = sub.tap(feats, row_off, 1, 63, 63, what)
+        act = _unpack(act.cpu(), key.split(".")[-1], dims, i)
+        want = torch.from_numpy(golden["stage/%s/%s" % (name, key)]).t()
+        errs[key] = _rel(act[:, :want.shape[1]], want)
+    pooled, emb = sub.tap(feats, row_off, 1, 63, 63, 101)
+    pooled = pooled.cpu()[0]
+    cp = dims["ccatp"]
+    want = torch.from_numpy(golden["stage/%s/pool" % name])
+    got = torch.cat([pooled[:ccat], pooled[cp:cp + ccat]])
+    errs["pool"] = _rel(got, want)
+    errs["embed"] = _rel(emb.cpu()[0], torch.from_numpy(golden["stage/%s/embed" % name]))
+    print(name, {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 1e-4, (k, errs)
+
+
+# ------------------------------------------------------------------------------------------ scoring / l2norm
+def test_cosine_trials_match_calculate_score(golden, meta):
+    segs = meta["score_segs"]
+    vecs = [synth.normal("score/vec%d" % i, (segs[i], 192), seed=2) for i in range(len(segs))]
+    vecs = [F.normalize(v, p=2, dim=1) if i % 2 == 0 else v for i, v in enumerate(vecs)]
+    lab, a, b = synth.trial_pairs(len(segs), 300, seed=2)
+    vectors = {"utt%03d" % i: v.to(DEV) for i, v in enumerate(vecs)}
+    trials = [{"label": int(l), "enroll": "utt%03d" % i, "test": "utt%03d" % j} for l, i, j in zip(lab, a, b)]
+    scores, labels, pairs = sugar_amd.score_trials(trials, vectors, mode="cosine", n_jobs=1)
+    want = golden["score/scores"]
+    assert scores.dtype == np.float64 and scores.shape == want.shape
+    assert np.abs(scores - want).max() < 2e-6
+    assert np.array_equal(labels, lab) and pairs[0] == [trials[0]["enroll"], trials[0]["test"]]
+    one = sugar_amd.calculate_score(vecs[3].to(DEV), vecs[8].to(DEV), "cosine")
+    assert abs(one - ref_cpu.cosine_score(vecs[3], vecs[8])) < 2e-6
+
+
+def test_cosine_tiny_norm_uses_eps_per_vector():
+    a = torch.tensor([[3e-9, 4e-9] + [0.0] * 190])
+    b = torch.tensor([[1.0, 2.0, 2.0] + [0.0] * 189])
+    got = sugar_amd.calculate_score(a.to(DEV), b.to(DEV))
+    assert abs(got - ref_cpu.cosine_score(a, b)) < 1e-6
+
+
+def test_l2norm_matches_f_normalize():
+    x = synth.normal("l2/x", (33, 192), seed=1)
+    x[5] = 0
+    xd = x.to(DEV).clone()
+    _lib.check(_lib.lib().sugar_l2norm(xd.data_ptr(), 33, 192, torch.cuda.current_stream().cuda_stream))
+    assert (xd.cpu() - F.normalize(x, p=2, dim=1)).abs().max() < 1e-6

@@ -1,0 +1,156 @@
+"""CPU: host-side mirror of the reference interface, checkpoint format, C-ABI surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import sugar_amd
+from conftest import ROOT, cfg_of
+from sugar_amd import _lib, layout, synth
+from sugar_amd.vectors import plan_batches, shard_indices
+
+
+def test_supernet_layout_is_the_reference_layout(meta, supernet):
+    assert [[k, list(v.shape)] for k, v in supernet.state_dict().items()] == meta["supernet_keys"]
+    assert sum(p.numel() for p in supernet.parameters()) == meta["supernet_numel"] == 7550818
+
+
+def test_clone_reproduces_reference_clone(golden, meta, supernet):
+    for name in meta["configs"]:
+        sub = supernet.clone(cfg_of(meta, name))
+        sd = sub.state_dict()
+        assert [[k, list(v.shape)] for k, v in sd.items()] == meta["subnet_keys"][name]
+        sums = np.array([float(v.double().sum()) for v in sd.values()])
+        assert np.allclose(sums, golden["clone_sums/" + name], rtol=1e-6, atol=1e-5), name
+    for key in golden.files:
+        if key.startswith("clone_tensor/"):
+            _, name, k = key.split("/", 2)
+            sd = supernet.clone(cfg_of(meta, name)).state_dict()
+            assert np.allclose(sd[k].numpy(), golden[key], rtol=1e-6, atol=1e-7), key
+    supernet.config = None
+
+
+def test_config_protocol(supernet):
+    supernet.config = None
+    assert supernet.config == (4, [512] * 5, [5] * 5, 1536)
+    supernet.config = layout.BASE
+    assert supernet.config[0] == 3 and supernet.active_catconv_channels == 1536
+    with pytest.raises(ValueError):
+        supernet.config = (5, [512] * 6, [5] * 6, 1536)          # deeper than the supernet
+    with pytest.raises(ValueError):
+        supernet.config = (3, [1024] * 4, [5] * 4, 1536)         # wider than the supernet
+    with pytest.raises(ValueError):
+        supernet.config = (3, [512] * 4, [7, 3, 3, 3], 1536)     # kernel not in the supernet
+    supernet.config = None
+
+
+def test_count_ops_params_known_answers(meta, supernet):
+    for key, (ops, params) in meta["count_ops_params"].items():
+        name, T = key.split("@")
+        supernet.config = cfg_of(meta, name)
+        assert supernet.count_ops([1, 80, int(T)]) == ops
+        assert supernet.count_params() == params
+    supernet.config = None
+
+
+def test_tdnnpath_sampler_stream(meta, supernet):
+    space = supernet.space(mode=["kernel", "depth", "width1", "width2"], verbose=False)
+    assert space == meta["tdnnpath_space"]
+    path = sugar_amd.TDNNPath(space)
+    got = [path.sample() for _ in range(16)]
+    assert [[d, list(c), list(k), cc] for d, c, k, cc in got] == meta["tdnnpath_samples"]
+
+
+def test_config_names():
+    name = "ecapa-tdnn.3.512.512.512.512.5.3.3.3.1536"
+    assert layout.config_from_name("depth." + name + ".bn.tar") == layout.BASE
+    assert layout.config_name(layout.BASE) == name
+
+
+def test_from_pretrained_checkpoint_format(tmp_path, sup_state, meta):
+    # supernet file: {'state_dict': {'module.__S__.*', 'module.__L__.W', 'module.__T__.*'}}; subnet file: {'subnet', 'bn', ...}
+    ck = {"module.__S__." + k: v for k, v in sup_state.items()}
+    ck["module.__L__.W"] = torch.zeros(192, 10)
+    ck["module.__T__.torchfb.0.weight"] = torch.tensor([[[-0.97, 1.0]]])
+    torch.save({"state_dict": ck, "epoch": 1}, tmp_path / "depth.torchparams")
+    shapes = layout.subnet_shapes(layout.BASE)
+    bn = synth.fill_state_dict({k: shapes[k] for k in meta["bn_file_keys"]}, seed=11)
+    torch.save({"subnet": layout.BASE, "bn": bn, "EER (%) w/o AS-Norm": "1.14"}, tmp_path / "base.bn.tar")
+    subnet, info = sugar_amd.WrappedModel.from_pretrained(str(tmp_path), "depth.torchparams", "base.bn.tar")
+    assert isinstance(subnet.module.__S__, sugar_amd.TDNNSubnet)
+    assert isinstance(subnet.module.__T__, sugar_amd.LogMelFbanks)
+    sd = subnet.module.__S__.state_dict()
+    assert torch.equal(sd["layer1.bn.running_mean"], bn["layer1.bn.running_mean"])        # BN file overrides the clone
+    assert torch.equal(sd["layer1.conv.weight"], sup_state["layer1.conv.conv.weight"])      # K0 = 5: no transform
+    assert info["subnet"]["subnet"] == layout.BASE
+    assert set(sugar_amd.bn_state_dict(subnet.module.__S__).keys()) == set(meta["bn_file_keys"])
+    with pytest.raises(ValueError):
+        sugar_amd.WrappedModel.from_pretrained(str(tmp_path), "depth.torchparams", "base.bn.tar", feat_type="mfcc")
+    with pytest.raises(ValueError):
+        sugar_amd.WrappedModel.from_pretrained(str(tmp_path), "depth.torchparams", "base.bn.tar", model_type="resnet")
+    with pytest.raises(FileNotFoundError):
+        sugar_amd.WrappedModel.from_pretrained(str(tmp_path), "missing.torchparams", "base.bn.tar")
+
+
+def test_no_cpu_fallback(supernet):
+    sub = supernet.clone(layout.SMALLEST)
+    with pytest.raises(_lib.SugarError):
+        sub(torch.zeros(1, 80, 63))
+    model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks()))
+    with pytest.raises(_lib.SugarError):
+        model(torch.zeros(1, 10000))
+    with pytest.raises(_lib.SugarError):
+        sugar_amd.scores.score_pairs(torch.zeros(2, 192), torch.zeros(3, dtype=torch.int32),
+                                     torch.zeros(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
+    supernet.config = None
+
+
+def test_cabi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "sugar_amd.h")).read()
+    declared = set(re.findall(r"\b(sugar_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert b"gfx950" in _lib.lib().sugar_version()
+    # argument checking that needs no GPU: NULL pointers are rejected with SUGAR_EINVAL and a message
+    rc = _lib.lib().sugar_cosine_trials(None, 192, None, 1, None, None, 1, None, None)
+    assert rc == -1 and b"null" in _lib.lib().sugar_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "sugar_cosine_trials")
+
+
+def test_struct_layout_matches_header():
+    # SugarBlock: 2 ints + first(1+4) + res(7 + 28) + last(1+4) + se(4) pointers
+    assert ctypes.sizeof(_lib.SugarBN) == 32
+    assert ctypes.sizeof(_lib.SugarBlock) == 8 + 8 * (5 + 35 + 5 + 4)
+    assert ctypes.sizeof(_lib.SugarSubnetDesc) == 32 + 8 * 5 + 8 * ctypes.sizeof(_lib.SugarBlock) + 8 * 3 + 32 + 16 + 32
+
+
+def test_batch_planning():
+    lengths = [32000, 320000, 48000, 48000, 100000, 64000]
+    batches = plan_batches(lengths, batch_size=4, max_frames=1200)
+    flat = sorted(i for b in batches for i in b)
+    assert flat == list(range(len(lengths)))
+    for b in batches:
+        assert len(b) <= 4
+        assert len(b) == 1 or sum(1 + lengths[i] // 160 for i in b) <= 1200
+    parts = [shard_indices(10, r, 4) for r in range(4)]
+    assert sorted(i for p in parts for i in p) == list(range(10))
+    w = [5, 1, 9, 3, 7, 2, 8]
+    parts = [shard_indices(7, r, 2, w) for r in range(2)]
+    assert sorted(i for p in parts for i in p) == list(range(7))
+    loads = [sum(w[i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= max(w)
+
+
+def test_batchplan_rejects_short_audio():
+    from sugar_amd.transforms import BatchPlan, num_frames
+    assert num_frames(48000) == 301 and num_frames(10000) == 63
+    with pytest.raises(ValueError):
+        BatchPlan([200], "cpu")
+    p = BatchPlan([10000, 48000], "cpu")
+    assert p.R == 364 and p.t_max == 301 and p.row_off.tolist() == [0, 63, 364] and p.wav_off.tolist() == [0, 10000]
