@@ -133,7 +133,7 @@ struct SELayer {            // device, f32, transposed for coalesced reads
   int c = 0, c_p = 0, hid = 0;
 };
 // scale[b][c] = sigmoid(W2 relu(W1 mean_t(y[b]) + b1) + b2)
-int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B,
+int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, float* d_mean,
                     float* d_scale, int dtype, hipStream_t s);
 // out = y * scale[b] + S ;  S += out (skipped when d_S_out == nullptr)
 int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, void* d_S, int ldS, void* d_out,
@@ -152,7 +152,9 @@ struct TailLayer {          // folded bnpool . linear . bnembed, f32
   float* bias = nullptr;    // [embed]
   int in_p = 0, embed = 0;
 };
-int launch_tail(const TailLayer& t, const float* d_pooled, int B, float* d_emb, hipStream_t s);
+int tail_splits(const TailLayer& t);   // k-splits of the tail GEMV = slabs of the partial buffer
+int launch_tail(const TailLayer& t, const float* d_pooled, int B, float* d_partial, float* d_emb, int normalize,
+                hipStream_t s);
 int launch_l2norm(float* d_x, int64_t n, int dim, hipStream_t s);
 
 // dtype -> f32 copy of a strided [R][C] activation (debug taps)

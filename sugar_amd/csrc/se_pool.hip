@@ -49,51 +49,91 @@ struct Chunk<bf16> {
 };
 
 // ------------------------------------------------------------------------------------------ SE scale
+// se_mean_kernel: grid (channel slabs of 8 chunks, utterances); 256 threads = 8 chunks x 32 row lanes.
 template <typename T>
-__global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ y, int ldy,
-                                                       const int32_t* __restrict__ row_off, SELayer se,
-                                                       float* __restrict__ scale) {
+__global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, int ldy, int c_p,
+                                                      const int32_t* __restrict__ row_off,
+                                                      float* __restrict__ mean) {
   constexpr int E = Chunk<T>::N;
-  extern __shared__ float sm[];          // partial [G][c_p] (<= 256*E floats) | mean [c_p] | hidden [hid]
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float partial[32][8 * E + 1];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int s = row_off[b], n = row_off[b + 1] - s;
-  const int nch = se.c_p / E;            // <= 256 (checked on the host)
-  const int G = 256 / nch;
-  const int ch = tid % nch, g = tid / nch;
-  float* partial = sm;
-  float* mean = sm + 256 * E;
-  float* hidden = mean + se.c_p;
+  const int tx = tid & 7, ty = tid >> 3;
+  const int c0 = (blockIdx.x * 8 + tx) * E;
   float acc[E];
 #pragma unroll
   for (int i = 0; i < E; ++i) acc[i] = 0.f;
-  if (g < G) {
-    const T* __restrict__ p = y + (size_t)s * ldy + ch * E;
-    for (int r = g; r < n; r += G) {
+  if (c0 < c_p) {
+    const T* __restrict__ p = y + (size_t)s * ldy + c0;
+#pragma unroll 4
+    for (int r = ty; r < n; r += 32) {
       float v[E];
       Chunk<T>::load(p + (size_t)r * ldy, v);
 #pragma unroll
       for (int i = 0; i < E; ++i) acc[i] += v[i];
     }
+  }
 #pragma unroll
-    for (int i = 0; i < E; ++i) partial[g * se.c_p + ch * E + i] = acc[i];
-  }
+  for (int i = 0; i < E; ++i) partial[ty][tx * E + i] = acc[i];
   __syncthreads();
-  for (int c = tid; c < se.c_p; c += 256) {
+  if (tid < 8 * E) {
+    const int c = blockIdx.x * 8 * E + tid;
+    if (c < c_p) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) t += partial[k][tid];
+      mean[(size_t)b * c_p + c] = t / (float)n;
+    }
+  }
+}
+
+// se_mlp_kernel: one 1024-thread workgroup per utterance; both tiny GEMVs split over k so no thread walks more
+// than ~64 weights, weights stored transposed so every load is coalesced.
+__global__ __launch_bounds__(1024) void se_mlp_kernel(const float* __restrict__ mean, SELayer se,
+                                                      float* __restrict__ scale) {
+  extern __shared__ float sm[];          // mean [c_p] | hidden [hid] | partial [1024]
+  float* m = sm;
+  float* hidden = sm + se.c_p;
+  float* part = hidden + se.hid;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < se.c_p; c += 1024) m[c] = mean[(size_t)b * se.c_p + c];
+  __syncthreads();
+  {  // hidden = relu(W1 mean + b1): thread (j, kp), kp-th slice of the channel range
+    const int KP = 1024 / se.hid > 0 ? 1024 / se.hid : 1;
+    const int j = tid % se.hid, kp = tid / se.hid;
     float t = 0.f;
-    for (int k = 0; k < G; ++k) t += partial[k * se.c_p + c];
-    mean[c] = t / (float)n;
+    if (kp < KP) {
+      const int per = (se.c + KP - 1) / KP;
+      const int i0 = kp * per, i1 = min(se.c, i0 + per);
+#pragma unroll 8
+      for (int i = i0; i < i1; ++i) t = fmaf(se.w1t[(size_t)i * se.hid + j], m[i], t);
+    }
+    part[tid] = t;
+    __syncthreads();
+    if (tid < se.hid) {
+      float t2 = se.b1[tid];
+      for (int k = 0; k < KP; ++k) t2 += part[k * se.hid + tid];
+      hidden[tid] = fmaxf(t2, 0.f);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int j = tid; j < se.hid; j += 256) {
-    float t = se.b1[j];
-    for (int i = 0; i < se.c; ++i) t = fmaf(se.w1t[(size_t)i * se.hid + j], mean[i], t);
-    hidden[j] = fmaxf(t, 0.f);
-  }
-  __syncthreads();
-  for (int c = tid; c < se.c_p; c += 256) {
-    float t = se.b2[c];
-    for (int j = 0; j < se.hid; ++j) t = fmaf(se.w2t[(size_t)j * se.c_p + c], hidden[j], t);
-    scale[(size_t)b * se.c_p + c] = 1.0f / (1.0f + expf(-t));
+  // scale = sigmoid(W2 hidden + b2): channel blocks of 256, 4 k-slices each
+  for (int cb = 0; cb < se.c_p; cb += 256) {
+    const int c = cb + (tid & 255), kp = tid >> 8;
+    float t = 0.f;
+    if (c < se.c_p) {
+      const int per = (se.hid + 3) / 4;
+      const int j0 = kp * per, j1 = min(se.hid, j0 + per);
+#pragma unroll 8
+      for (int j = j0; j < j1; ++j) t = fmaf(se.w2t[(size_t)j * se.c_p + c], hidden[j], t);
+    }
+    part[tid] = t;
+    __syncthreads();
+    if (tid < 256 && c < se.c_p) {
+      const float z = se.b2[c] + part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid];
+      scale[(size_t)b * se.c_p + c] = 1.0f / (1.0f + expf(-z));
+    }
+    __syncthreads();
   }
 }
 
@@ -232,38 +272,66 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const T* __restrict__ a
 }
 
 // ------------------------------------------------------------------------------------------ tail
-constexpr int TAIL_U = 4;
+constexpr int TAIL_U = 16;    // utterances per workgroup
+constexpr int TAIL_K = 512;   // pooled features per k-split
 
-__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ wt, const float* __restrict__ bias,
-                                                   int in_p, int embed, const float* __restrict__ pooled, int B,
-                                                   float* __restrict__ emb) {
+// partial[ks][b][o] = sum_{i in k-split ks} wt[i][o] * pooled[b][i]
+__global__ __launch_bounds__(256) void tail_partial_kernel(const float* __restrict__ wt, int in_p, int embed,
+                                                           const float* __restrict__ pooled, int B,
+                                                           float* __restrict__ partial) {
+  __shared__ float ps[TAIL_U][TAIL_K];
   __shared__ float red[4][TAIL_U][64];
-  const int o = blockIdx.y * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
+  const int tid = threadIdx.x, ol = tid & 63, kl = tid >> 6;
+  const int o = blockIdx.y * 64 + ol;
   const int b0 = blockIdx.x * TAIL_U;
-  const bool o_ok = o < embed;
+  const int k0 = blockIdx.z * TAIL_K;
+  const int kn = min(TAIL_K, in_p - k0);
+  for (int idx = tid; idx < TAIL_U * TAIL_K; idx += 256) {
+    const int u = idx / TAIL_K, i = idx - u * TAIL_K;
+    ps[u][i] = (b0 + u < B && i < kn) ? pooled[(size_t)(b0 + u) * in_p + k0 + i] : 0.f;
+  }
+  __syncthreads();
   float acc[TAIL_U];
 #pragma unroll
   for (int u = 0; u < TAIL_U; ++u) acc[u] = 0.f;
-  const float* pu[TAIL_U];
+  const bool o_ok = o < embed;
+#pragma unroll 4
+  for (int i = kl; i < kn; i += 4) {
+    const float w = o_ok ? wt[(size_t)(k0 + i) * embed + o] : 0.f;
 #pragma unroll
-  for (int u = 0; u < TAIL_U; ++u) pu[u] = pooled + (size_t)min(b0 + u, B - 1) * in_p;
-  for (int i = kl; i < in_p; i += 4) {
-    const float w = o_ok ? wt[(size_t)i * embed + o] : 0.f;
-#pragma unroll
-    for (int u = 0; u < TAIL_U; ++u) acc[u] = fmaf(w, pu[u][i], acc[u]);
+    for (int u = 0; u < TAIL_U; ++u) acc[u] = fmaf(w, ps[u][i], acc[u]);
   }
 #pragma unroll
-  for (int u = 0; u < TAIL_U; ++u) red[kl][u][threadIdx.x & 63] = acc[u];
+  for (int u = 0; u < TAIL_U; ++u) red[kl][u][ol] = acc[u];
   __syncthreads();
-  if (kl == 0 && o_ok) {
-#pragma unroll
-    for (int u = 0; u < TAIL_U; ++u) {
-      if (b0 + u < B) {
-        const int x = threadIdx.x & 63;
-        emb[(size_t)(b0 + u) * embed + o] = red[0][u][x] + red[1][u][x] + red[2][u][x] + red[3][u][x] + bias[o];
-      }
-    }
+  for (int idx = tid; idx < TAIL_U * 64; idx += 256) {
+    const int u = idx >> 6, x = idx & 63;
+    const int oo = blockIdx.y * 64 + x;
+    if (b0 + u < B && oo < embed)
+      partial[((size_t)blockIdx.z * B + b0 + u) * embed + oo] = red[0][u][x] + red[1][u][x] + red[2][u][x] + red[3][u][x];
   }
+}
+
+// emb[b][o] = bias[o] + sum_ks partial[ks][b][o]; optional F.normalize(p=2, dim=1, eps=1e-12)
+__global__ __launch_bounds__(256) void tail_finalize_kernel(const float* __restrict__ partial, int ks, int B,
+                                                            int embed, const float* __restrict__ bias,
+                                                            int normalize, float* __restrict__ emb) {
+  __shared__ float wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float ss = 0.f;
+  for (int o = tid; o < embed; o += 256) {
+    float t = bias[o];
+    for (int k = 0; k < ks; ++k) t += partial[((size_t)k * B + b) * embed + o];
+    emb[(size_t)b * embed + o] = t;
+    ss = fmaf(t, t, ss);
+  }
+  if (!normalize) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  const float inv = 1.0f / fmaxf(sqrtf(wsum[0] + wsum[1] + wsum[2] + wsum[3]), 1e-12f);
+  for (int o = tid; o < embed; o += 256) emb[(size_t)b * embed + o] *= inv;
 }
 
 __global__ __launch_bounds__(64) void l2norm_kernel(float* __restrict__ x, int dim) {
@@ -278,19 +346,19 @@ __global__ __launch_bounds__(64) void l2norm_kernel(float* __restrict__ x, int d
 
 }  // namespace
 
-int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, float* d_scale,
-                    int dtype, hipStream_t s) {
+int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, float* d_mean,
+                    float* d_scale, int dtype, hipStream_t s) {
   const int E = dtype == SUGAR_F32 ? 4 : 8;
-  SUGAR_CHECK_ARG(se.c_p % E == 0 && se.c_p / E <= 256 && se.c_p / E > 0, "se: channels %d unsupported (max %d)",
-                  se.c_p, 256 * E);
-  SUGAR_CHECK_ARG(se.hid > 0 && ldy % E == 0, "se: bad hidden %d / ld %d", se.hid, ldy);
-  const size_t smem = (256 * E + se.c_p + se.hid) * sizeof(float);
+  SUGAR_CHECK_ARG(se.c_p % E == 0 && se.c_p > 0, "se: channels %d unsupported", se.c_p);
+  SUGAR_CHECK_ARG(se.hid > 0 && se.hid <= 1024 && ldy % E == 0, "se: bad hidden %d / ld %d", se.hid, ldy);
+  const dim3 grid((unsigned)ceil_div(se.c_p / E, 8), (unsigned)B);
   if (dtype == SUGAR_F32)
-    hipLaunchKernelGGL(se_scale_kernel<float>, dim3(B), dim3(256), smem, s, (const float*)d_y, ldy, d_row_off, se,
-                       d_scale);
+    hipLaunchKernelGGL(se_mean_kernel<float>, grid, dim3(256), 0, s, (const float*)d_y, ldy, se.c_p, d_row_off, d_mean);
   else
-    hipLaunchKernelGGL(se_scale_kernel<bf16>, dim3(B), dim3(256), smem, s, (const bf16*)d_y, ldy, d_row_off, se,
-                       d_scale);
+    hipLaunchKernelGGL(se_mean_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_y, ldy, se.c_p, d_row_off, d_mean);
+  SUGAR_LAUNCH_CHECK();
+  const size_t smem = (se.c_p + se.hid + 1024) * sizeof(float);
+  hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(1024), smem, s, d_mean, se, d_scale);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
@@ -326,9 +394,16 @@ int launch_pool_stats(const PoolLayer& P, const void* d_a, int lda, const void* 
   return SUGAR_OK;
 }
 
-int launch_tail(const TailLayer& t, const float* d_pooled, int B, float* d_emb, hipStream_t s) {
-  const dim3 grid((unsigned)ceil_div(B, TAIL_U), (unsigned)ceil_div(t.embed, 64));
-  hipLaunchKernelGGL(tail_kernel, grid, dim3(256), 0, s, t.wt, t.bias, t.in_p, t.embed, d_pooled, B, d_emb);
+int tail_splits(const TailLayer& t) { return (int)ceil_div(t.in_p, TAIL_K); }
+
+int launch_tail(const TailLayer& t, const float* d_pooled, int B, float* d_partial, float* d_emb, int normalize,
+                hipStream_t s) {
+  const int ks = tail_splits(t);
+  const dim3 grid((unsigned)ceil_div(B, TAIL_U), (unsigned)ceil_div(t.embed, 64), (unsigned)ks);
+  hipLaunchKernelGGL(tail_partial_kernel, grid, dim3(256), 0, s, t.wt, t.in_p, t.embed, d_pooled, B, d_partial);
+  SUGAR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tail_finalize_kernel, dim3(B), dim3(256), 0, s, d_partial, ks, B, t.embed, t.bias, normalize,
+                     d_emb);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }

@@ -239,7 +239,7 @@ struct Workspace {
   int2* rowseg;
   float* logmel;
   void *feats, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
-  float *sescale, *pooled;
+  float *semean, *sescale, *pooled, *tailpart;
   int64_t bytes;
 };
 
@@ -262,8 +262,10 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   w.ybuf = take(R * n->c0p * esz);
   w.hbuf = take(R * n->ccatp * esz);
   w.abuf = take(R * n->bott * esz);
+  w.semean = (float*)take((int64_t)B * n->c0p * 4);
   w.sescale = (float*)take((int64_t)B * n->c0p * 4);
   w.pooled = (float*)take((int64_t)B * 2 * n->ccatp * 4);
+  w.tailpart = (float*)take((int64_t)tail_splits(n->tail) * B * n->embed * 4);
   w.bytes = off;
   return w;
 }
@@ -312,7 +314,7 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
     { Prof p(SUGAR_STAGE_LAST, s); if ((rc = launch_conv(b.last, l, w.rowseg, R, dt, s))) return rc; }
     if ((rc = tapcopy(3 + 4 * i, w.ybuf, n->c0p, n->c0p))) return rc;
-    { Prof p(SUGAR_STAGE_SE_SCALE, s); if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, w.sescale, dt, s))) return rc; }
+    { Prof p(SUGAR_STAGE_SE_SCALE, s); if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, w.semean, w.sescale, dt, s))) return rc; }
     void* out = col(w.cat, (int64_t)i * n->c0p);
     {
       Prof p(SUGAR_STAGE_SE_APPLY, s);
@@ -334,8 +336,7 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
   if (tap == 101 && tap_out)
     SUGAR_HIP(hipMemcpyAsync(tap_out, w.pooled, (size_t)B * 2 * n->ccatp * 4, hipMemcpyDeviceToDevice, s));
   Prof p(SUGAR_STAGE_TAIL, s);
-  if ((rc = launch_tail(n->tail, w.pooled, B, d_emb, s))) return rc;
-  if (normalize && (rc = launch_l2norm(d_emb, B, n->embed, s))) return rc;
+  if ((rc = launch_tail(n->tail, w.pooled, B, w.tailpart, d_emb, normalize, s))) return rc;
   return SUGAR_OK;
 }
 
