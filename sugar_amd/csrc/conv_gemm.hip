@@ -237,10 +237,15 @@ static int launch_conv_t(const ConvArgs& a0, hipStream_t s) {
   return SUGAR_OK;
 }
 
+bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype);
+int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t s);
+
 int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s) {
   const int epc = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(R > 0 && R < (1ll << 31), "conv: bad row count %lld", (long long)R);
   SUGAR_CHECK_ARG(L.w && io.x && io.y && d_rowseg, "conv: null pointer");
+  SUGAR_CHECK_ARG(((uintptr_t)io.x & 15) == 0 && io.ldx % epc == 0, "conv: activation pointer / ld must be 16-byte aligned");
+  if (gemm1x1_eligible(L, io, dtype)) return launch_gemm1x1(L, io, R, s);   // wide 1x1 convs: LDS-DMA 256^2 GEMM
   SUGAR_CHECK_ARG(L.cin_p % epc == 0 && io.ldx % epc == 0 && io.ldy % 4 == 0 && L.cout % 4 == 0,
                   "conv: channel counts must be multiples of the 16-byte chunk (cin_p %d ldx %d ldy %d cout %d)",
                   L.cin_p, io.ldx, io.ldy, L.cout);
@@ -269,7 +274,7 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
   SUGAR_CHECK_ARG(cin_p % epc == 0 && cout_p % 4 == 0 && cin_p >= cin && cout_p >= cout, "pack_conv: bad padding");
   const int bke = 8 * epc;
   L->cout = cout_p;
-  L->n_pad = (int)(cout_p <= 64 ? 64 : round_up(cout_p, 128));
+  L->n_pad = (int)(cout_p <= 64 ? 64 : (cout_p <= 128 ? 128 : round_up(cout_p, 256)));
   L->cin_p = cin_p;
   L->ktaps = k;
   L->dil = dil;
