@@ -4,16 +4,17 @@
 // (:50-52: torch.stft n_fft 512 / hop 160 / periodic Hamming(400) centred in the 512 frame / center=True reflect
 // padding, |X|^2, HTK triangular mel filters 20..7600 Hz, norm=None) -> +1e-6 -> log -> InstanceNorm1d(80).
 //
-// Kernel 1 (fbank_dft_kernel): one workgroup = 64 frames of one utterance.
-//   * the 10 480 samples the 64 frames touch are loaded once, reflect-padded at the utterance's true ends and
-//     pre-emphasised on the fly, into LDS (skewed by 4 floats per 160 so the per-frame fragment reads of the
-//     MFMA A operand are bank-conflict free);
-//   * the windowed DFT is an exact-f32 MFMA GEMM  [64 frames x 400] . [400 x (256 cos | 256 sin)]  with
-//     v_mfma_f32_32x32x2_f32; the Hamming window is folded into the basis, whose layout is pre-permuted so every
-//     lane fetches its B fragments for 4 consecutive MFMAs with one 16-byte load (bins 0..255 only: the Nyquist
-//     bin has zero mel weight because f_max = 7600 Hz < 8000 Hz);
-//   * power = re^2 + im^2 goes to LDS, the 477-tap sparse mel projection and log run on the VALU, and the
-//     [64 x 80] log-mel tile leaves through LDS as one contiguous, coalesced 20 KB store.
+// Kernel 1 (fbank_fft_kernel): one workgroup = 32 frames of one utterance, HBM-bound by design (each sample is read
+// once, each log-mel value written once: 288 320 B per 3 s utterance).
+//   * the 5 360 samples the 32 frames touch are loaded once into LDS, reflect-padded at the utterance's true ends
+//     and pre-emphasised on the fly;
+//   * each wavefront transforms one frame at a time: the 512-point real FFT is a 256-point complex FFT of
+//     z[m] = x[2m] + i x[2m+1] (the window only covers 400 samples; a frame's position inside the 512-point buffer
+//     only changes the phase, not |X|^2), done as 4 radix-4 Stockham passes with one butterfly per lane and the
+//     exchange between passes through 4 KB of wave-private LDS; window and twiddle factors live in registers;
+//   * split-radix post-processing X[k] = E[k] + W512^k O[k], |X|^2 for bins 0..255 (the Nyquist bin has zero mel
+//     weight: f_max = 7600 Hz < 8000 Hz), the 477-tap sparse mel projection and log run on the VALU;
+//   * the [32 x 80] log-mel tile leaves through LDS as one contiguous, coalesced 10 KB store.
 // Kernel 2 (instnorm_kernel): per utterance and mel bin, mean / biased variance over the true frames (two-pass),
 //   (x - mean) / sqrt(var + 1e-5), written channels-last [R][80] in the compute dtype.
 #include <math.h>
@@ -28,16 +29,14 @@ namespace sugar {
 namespace {
 constexpr int NFFT = 512, WIN = 400, HOP = SUGAR_HOP, NMEL = SUGAR_N_MELS;
 constexpr int NBIN = 256;                 // bins 0..255
-constexpr int FRAMES = 64;                // frames per workgroup
-constexpr int SPAN = (FRAMES - 1) * HOP + WIN;          // 10480 samples
-constexpr int SAMPLE_LDS = SPAN + 4 * (SPAN / HOP + 1);  // skewed
-constexpr int PLD = NBIN + 1;             // power tile leading dim (odd: conflict-free column walks)
-constexpr int KQ = WIN / 8;               // 50 k-groups of 8
-constexpr int MEL_MAXW = 24;              // max non-zero taps of one mel filter (17 for this filterbank)
+constexpr int FRAMES = 32;                // frames per workgroup
+constexpr int SPAN = (FRAMES - 1) * HOP + WIN;   // 5360 samples
+constexpr int MEL_MAXW = 20;              // max non-zero taps of one mel filter (17 for this filterbank)
 constexpr int SLD = NMEL + 1;
 
 struct FbankTables {
-  float* basis = nullptr;    // [KQ][2 (lane half)][2 (cos, sin)][NBIN][4]
+  float2* tw = nullptr;      // [512] exp(-2 pi i n / 512)
+  float* win = nullptr;      // [512] periodic Hamming(400), zero for n >= 400
   int* mel_lo = nullptr;     // [NMEL]
   int* mel_cnt = nullptr;    // [NMEL]
   float* mel_w = nullptr;    // [NMEL][MEL_MAXW]
@@ -55,19 +54,14 @@ int get_tables(FbankTables* out) {
   std::lock_guard<std::mutex> lk(g_mu);
   if ((int)g_tables.size() <= dev) g_tables.resize(dev + 1);
   FbankTables& t = g_tables[dev];
-  if (!t.basis) {
-    std::vector<float> basis((size_t)KQ * 2 * 2 * NBIN * 4);
+  if (!t.tw) {
     const double PI = 3.14159265358979323846;
-    for (int q = 0; q < KQ; ++q)
-      for (int h = 0; h < 2; ++h)
-        for (int col = 0; col < NBIN; ++col)
-          for (int i = 0; i < 4; ++i) {
-            const int n = 8 * q + 4 * h + i;
-            const double w = 0.54 - 0.46 * cos(2.0 * PI * n / WIN);   // torch.hamming_window(400), periodic
-            const double ph = 2.0 * PI * (double)((col * n) % NFFT) / NFFT;
-            basis[((((size_t)q * 2 + h) * 2 + 0) * NBIN + col) * 4 + i] = (float)(w * cos(ph));
-            basis[((((size_t)q * 2 + h) * 2 + 1) * NBIN + col) * 4 + i] = (float)(w * sin(ph));
-          }
+    std::vector<float> tw(2 * NFFT), win(NFFT, 0.f);
+    for (int n = 0; n < NFFT; ++n) {
+      tw[2 * n] = (float)cos(2.0 * PI * n / NFFT);
+      tw[2 * n + 1] = (float)(-sin(2.0 * PI * n / NFFT));
+    }
+    for (int n = 0; n < WIN; ++n) win[n] = (float)(0.54 - 0.46 * cos(2.0 * PI * n / WIN));  // torch.hamming_window(400)
     // torchaudio.functional.melscale_fbanks(257, 20, 7600, 80, 16000, norm=None, mel_scale="htk")
     std::vector<int> lo(NMEL), cnt(NMEL);
     std::vector<float> mw((size_t)NMEL * MEL_MAXW, 0.f);
@@ -91,8 +85,10 @@ int get_tables(FbankTables* out) {
       lo[m] = first < 0 ? 0 : first;
       cnt[m] = n;
     }
-    SUGAR_HIP(hipMalloc(&t.basis, basis.size() * sizeof(float)));
-    SUGAR_HIP(hipMemcpy(t.basis, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice));
+    SUGAR_HIP(hipMalloc(&t.tw, tw.size() * sizeof(float)));
+    SUGAR_HIP(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    SUGAR_HIP(hipMalloc(&t.win, win.size() * sizeof(float)));
+    SUGAR_HIP(hipMemcpy(t.win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
     SUGAR_HIP(hipMalloc(&t.mel_lo, NMEL * sizeof(int)));
     SUGAR_HIP(hipMemcpy(t.mel_lo, lo.data(), NMEL * sizeof(int), hipMemcpyHostToDevice));
     SUGAR_HIP(hipMalloc(&t.mel_cnt, NMEL * sizeof(int)));
@@ -104,17 +100,30 @@ int get_tables(FbankTables* out) {
   return SUGAR_OK;
 }
 
-__device__ __forceinline__ int sample_addr(int p) { return p + 4 * (p / HOP); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
 
-__global__ __launch_bounds__(256, 2) void fbank_dft_kernel(const float* __restrict__ wav,
-                                                           const int64_t* __restrict__ wav_off,
-                                                           const int32_t* __restrict__ wav_len,
-                                                           const int32_t* __restrict__ row_off, FbankTables tb,
-                                                           float* __restrict__ logmel) {
-  // one LDS array, three lives: samples -> power tile -> log-mel staging
-  __shared__ __attribute__((aligned(16))) float lds[FRAMES * PLD];
-  static_assert(FRAMES * PLD >= SAMPLE_LDS, "power tile must cover the sample buffer");
-  static_assert(FRAMES * PLD >= FRAMES * SLD, "power tile must cover the staging tile");
+// in-place DFT of size 4 (forward, e^{-2 pi i u t / 4}):  y0 = a+b+c+d, y1 = a - i b - c + i d, y2 = a-b+c-d, y3 = a + i b - c - i d
+__device__ __forceinline__ void fft4(float2& a, float2& b, float2& c, float2& d) {
+  const float2 s0 = make_float2(a.x + c.x, a.y + c.y), d0 = make_float2(a.x - c.x, a.y - c.y);
+  const float2 s1 = make_float2(b.x + d.x, b.y + d.y), d1 = make_float2(b.x - d.x, b.y - d.y);
+  a = make_float2(s0.x + s1.x, s0.y + s1.y);
+  c = make_float2(s0.x - s1.x, s0.y - s1.y);
+  b = make_float2(d0.x + d1.y, d0.y - d1.x);   // d0 - i d1
+  d = make_float2(d0.x - d1.y, d0.y + d1.x);   // d0 + i d1
+}
+
+__global__ __launch_bounds__(256) void fbank_fft_kernel(const float* __restrict__ wav,
+                                                        const int64_t* __restrict__ wav_off,
+                                                        const int32_t* __restrict__ wav_len,
+                                                        const int32_t* __restrict__ row_off, FbankTables tb,
+                                                        float* __restrict__ logmel) {
+  __shared__ __attribute__((aligned(16))) float samples[SPAN];
+  // per wave ONE 2 KB exchange buffer: every pass reads its 4 inputs into registers before it writes, and a
+  // wavefront's LDS instructions execute in program order, so passes run in place; |X|^2 reuses the same bytes
+  __shared__ __attribute__((aligned(16))) float2 fbuf[4][NBIN];
+  __shared__ float tile[FRAMES * SLD];
 
   const int b = blockIdx.y;
   const int row0 = row_off[b];
@@ -123,89 +132,118 @@ __global__ __launch_bounds__(256, 2) void fbank_dft_kernel(const float* __restri
   if (t0 >= T) return;                               // uniform per workgroup
   const int L = wav_len[b];
   const float* __restrict__ x = wav + wav_off[b];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, j = tid & 63, wv = tid >> 6;
+  const int nf = min(FRAMES, T - t0);
 
-  // ---- stage pre-emphasised, reflect-padded samples --------------------------------------------
+  // ---- stage pre-emphasised, reflect-padded samples + the mel weights ------------------------------
   const int base = t0 * HOP - WIN / 2;               // original index of buffer position 0 (= t0*160 - 256 + 56)
-  for (int p = tid; p < SPAN; p += 256) {
+  const int span = (nf - 1) * HOP + WIN;
+  for (int p = tid; p < span; p += 256) {
     int idx = base + p;
     if (idx < 0) idx = -idx;                         // reflect (torch.stft center=True, pad_mode="reflect")
     if (idx >= L) idx = 2 * (L - 1) - idx;
-    idx = min(max(idx, 0), L - 1);                   // frames past T of the last tile: keep loads in bounds
+    idx = min(max(idx, 0), L - 1);
     const int prev = idx > 0 ? idx - 1 : 1;          // PreEmphasis reflect pad (1, 0): x[-1] := x[1]
-    lds[sample_addr(p)] = x[idx] - 0.97f * x[min(prev, L - 1)];
+    samples[p] = x[idx] - 0.97f * x[min(prev, L - 1)];
   }
+
+  // ---- per-lane constants: window taps, twiddles of passes 1..3, W512^k of the real-FFT split -------
+  float2 wn[4];                                      // window at samples 2m, 2m+1, m = j + 64 t
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wn[t] = make_float2(tb.win[2 * (j + 64 * t)], tb.win[2 * (j + 64 * t) + 1]);
+  float2 tw1[3], tw2[3], tw3[3], twp[4];
+#pragma unroll
+  for (int t = 1; t < 4; ++t) {
+    tw1[t - 1] = tb.tw[(t * (j & 3) * 32) & 511];    // exp(-2 pi i t k / 16),  k = j % 4
+    tw2[t - 1] = tb.tw[(t * (j & 15) * 8) & 511];    // exp(-2 pi i t k / 64),  k = j % 16
+    tw3[t - 1] = tb.tw[(t * j * 2) & 511];           // exp(-2 pi i t k / 256), k = j
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) twp[t] = tb.tw[j + 64 * t];
+  const int mel0 = j, mel1 = 64 + j;                 // lanes 0..15 own a second mel bin
+  const int lo0 = tb.mel_lo[mel0], cnt0 = tb.mel_cnt[mel0];
+  const int lo1 = j < NMEL - 64 ? tb.mel_lo[mel1] : 0, cnt1 = j < NMEL - 64 ? tb.mel_cnt[mel1] : 0;
   __syncthreads();
 
-  // ---- windowed DFT on the f32 matrix cores ----------------------------------------------------
-  // wave wv owns bins [64 wv, 64 wv + 64): 2 bin tiles x (cos, sin) x 2 frame tiles = 8 accumulators
-  f32x16 acc[2][2][2];
+  float2* A = fbuf[wv];
+  float2* Bf = fbuf[wv];
+  float* pw = (float*)fbuf[wv];
+  const float* __restrict__ melw = tb.mel_w;
+  for (int f = wv; f < nf; f += 4) {
+    const float2* sp = (const float2*)(samples + f * HOP);    // 160 f floats: 8-byte aligned
+    float2 v0, v1, v2, v3;
+    // pass 0 (Ns = 1, no twiddles): z[m] = x[2m] w[2m] + i x[2m+1] w[2m+1], zero beyond the 400-sample window
+    {
+      const float2 s0 = sp[j], s1 = sp[j + 64], s2 = sp[j + 128];
+      const float2 s3 = j < 8 ? sp[j + 192] : make_float2(0.f, 0.f);
+      v0 = make_float2(s0.x * wn[0].x, s0.y * wn[0].y);
+      v1 = make_float2(s1.x * wn[1].x, s1.y * wn[1].y);
+      v2 = make_float2(s2.x * wn[2].x, s2.y * wn[2].y);
+      v3 = make_float2(s3.x * wn[3].x, s3.y * wn[3].y);
+      fft4(v0, v1, v2, v3);
+      float2* o = A + 4 * j;
+      o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // pass 1 (Ns = 4)
+    {
+      v0 = A[j]; v1 = cmul(A[j + 64], tw1[0]); v2 = cmul(A[j + 128], tw1[1]); v3 = cmul(A[j + 192], tw1[2]);
+      fft4(v0, v1, v2, v3);
+      float2* o = Bf + ((j >> 2) << 4) + (j & 3);
+      o[0] = v0; o[4] = v1; o[8] = v2; o[12] = v3;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // pass 2 (Ns = 16)
+    {
+      v0 = Bf[j]; v1 = cmul(Bf[j + 64], tw2[0]); v2 = cmul(Bf[j + 128], tw2[1]); v3 = cmul(Bf[j + 192], tw2[2]);
+      fft4(v0, v1, v2, v3);
+      float2* o = A + ((j >> 4) << 6) + (j & 15);
+      o[0] = v0; o[16] = v1; o[32] = v2; o[48] = v3;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // pass 3 (Ns = 64): natural-order Z[0..255] lands in Bf
+    {
+      v0 = A[j]; v1 = cmul(A[j + 64], tw3[0]); v2 = cmul(A[j + 128], tw3[1]); v3 = cmul(A[j + 192], tw3[2]);
+      fft4(v0, v1, v2, v3);
+      Bf[j] = v0; Bf[j + 64] = v1; Bf[j + 128] = v2; Bf[j + 192] = v3;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // real-FFT split: E = (Z[k] + conj Z[256-k]) / 2, O = -i (Z[k] - conj Z[256-k]) / 2, X = E + W512^k O
+    float2 zks[4], zms[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < 4; ++t) {
+      zks[t] = Bf[j + 64 * t];
+      zms[t] = Bf[(NBIN - j - 64 * t) & (NBIN - 1)];
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][k][e] = 0.f;
-
-  const int fr = lane & 31, fh = lane >> 5;
-  const float* __restrict__ bptr = tb.basis + ((size_t)fh * 2 * NBIN + wv * 64 + fr) * 4;
-#pragma unroll 2
-  for (int q = 0; q < KQ; ++q) {
-    const int n0 = 8 * q + 4 * fh;
-    f32x4 af[2], bf[2][2];
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft) af[ft] = *(const f32x4*)&lds[sample_addr((ft * 32 + fr) * HOP + n0)];
-    const float* bq = bptr + (size_t)q * (2 * 2 * NBIN * 4);
-#pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-      for (int part = 0; part < 2; ++part) bf[bt][part] = *(const f32x4*)(bq + ((size_t)part * NBIN + bt * 32) * 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-          for (int part = 0; part < 2; ++part)
-            acc[ft][bt][part] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ft][i], bf[bt][part][i], acc[ft][bt][part], 0, 0, 0);
-  }
-  __syncthreads();   // every wave is done with the sample buffer
-
-  // ---- power spectrum -> LDS [frame][bin] -------------------------------------------------------
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int f = ft * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        const float re = acc[ft][bt][0][e], im = acc[ft][bt][1][e];
-        lds[f * PLD + wv * 64 + bt * 32 + fr] = re * re + im * im;
+    for (int t = 0; t < 4; ++t) {
+      const int k = j + 64 * t;
+      const float2 zk = zks[t], zm = zms[t];
+      const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+      const float2 d = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));   // (Z - conj Zm) / 2
+      const float2 o = make_float2(d.y, -d.x);                                     // -i d
+      const float2 wo = cmul(twp[t], o);
+      const float re = e.x + wo.x, im = e.y + wo.y;
+      pw[k] = re * re + im * im;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // sparse mel projection + log
+    {
+      float s = 0.f;
+      for (int i = 0; i < cnt0; ++i) s = fmaf(pw[lo0 + i], melw[mel0 * MEL_MAXW + i], s);
+      tile[f * SLD + mel0] = logf(s + 1e-6f);
+      if (j < NMEL - 64) {
+        float s2 = 0.f;
+        for (int i = 0; i < cnt1; ++i) s2 = fmaf(pw[lo1 + i], melw[mel1 * MEL_MAXW + i], s2);
+        tile[f * SLD + mel1] = logf(s2 + 1e-6f);
       }
-  __syncthreads();
-
-  // ---- sparse mel projection + log: thread = (frame tid & 63, 20 mel bins) ----------------------
-  const int f = tid & 63, mg = tid >> 6;
-  float out[NMEL / 4];
-#pragma unroll 1
-  for (int j = 0; j < NMEL / 4; ++j) {
-    const int m = mg * (NMEL / 4) + j;
-    const int lo = tb.mel_lo[m], cnt = tb.mel_cnt[m];
-    const float* __restrict__ wts = tb.mel_w + m * MEL_MAXW;
-    float s = 0.f;
-    for (int i = 0; i < cnt; ++i) s = fmaf(lds[f * PLD + lo + i], wts[i], s);
-    out[j] = logf(s + 1e-6f);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();   // power tile fully consumed
-#pragma unroll
-  for (int j = 0; j < NMEL / 4; ++j) lds[f * SLD + mg * (NMEL / 4) + j] = out[j];
   __syncthreads();
-  const int nf = min(FRAMES, T - t0);
   float* __restrict__ dst = logmel + (size_t)(row0 + t0) * NMEL;
-  for (int i = tid; i < nf * NMEL; i += 256) dst[i] = lds[(i / NMEL) * SLD + (i % NMEL)];
+  for (int i = tid; i < nf * NMEL; i += 256) dst[i] = tile[(i / NMEL) * SLD + (i % NMEL)];
 }
 
 constexpr int NORM_LANES = 8;   // row lanes per mel bin
@@ -258,7 +296,7 @@ int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_
   FbankTables tb;
   int rc = get_tables(&tb);
   if (rc) return rc;
-  hipLaunchKernelGGL(fbank_dft_kernel, dim3((unsigned)ceil_div(t_max, FRAMES), (unsigned)B), dim3(256), 0, s, d_wav,
+  hipLaunchKernelGGL(fbank_fft_kernel, dim3((unsigned)ceil_div(t_max, FRAMES), (unsigned)B), dim3(256), 0, s, d_wav,
                      d_wav_off, d_wav_len, d_row_off, tb, d_logmel);
   SUGAR_LAUNCH_CHECK();
   if (dtype == SUGAR_F32)

@@ -1,0 +1,195 @@
+// Attentive statistics pooling (gfx950): DynamicAttentiveStatsPool.forward (sugar/models/dynamictdnn.py:505-515)
+// after linear1 + tanh, as ONE kernel:
+//     logits = W2 . a          (K = 128 bottleneck, MFMA)
+//     alpha  = softmax over the utterance's frames, per channel
+//     mean   = sum_t alpha h,   std = sqrt(clamp(sum_t alpha h^2 - mean^2, 1e-9))
+// The accumulator is laid out [frame][channel] (A operand = a rows, B operand = W2 rows), so every lane owns one
+// channel and 16 frames of each 32-frame tile: softmax / weighted sums are an in-lane online-softmax recurrence,
+// logits and alpha never exist in memory, and h -- the largest activation of the network -- is read exactly once.
+//
+// One workgroup = 8 waves = (utterance, 256 channels).  Per 32-frame tile the a tile [32 x 128] and the h tile
+// [32 x 256] are staged through LDS with 16-byte coalesced loads (register prefetch of tile t+1 during tile t, two LDS
+// buffers, one barrier per tile); chunk index XOR (row & 15) keeps the ds_read_b128 fragment reads conflict-free.
+#include "common.h"
+
+namespace sugar {
+namespace {
+
+template <typename T>
+struct PoolMma;
+template <>
+struct PoolMma<bf16> {
+  typedef bf16x8 Frag;
+  static constexpr int E = 8;
+  static constexpr int NG = 8;   // k-groups: 128 / 16
+  __device__ __forceinline__ static void mma(f32x16& acc, const Frag& a, const Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <>
+struct PoolMma<float> {
+  typedef f32x4 Frag;
+  static constexpr int E = 4;
+  static constexpr int NG = 16;  // 128 / 8
+  __device__ __forceinline__ static void mma(f32x16& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+  }
+};
+
+constexpr int PT = 32;     // frames per tile
+constexpr int PC = 256;    // channels per workgroup
+constexpr int BOTT = 128;
+
+template <typename T>
+__global__ __launch_bounds__(512) void pool_stats_kernel(const T* __restrict__ a, int lda, const T* __restrict__ h,
+                                                         int ldh, const T* __restrict__ w2, int ccat_p,
+                                                         const int32_t* __restrict__ row_off,
+                                                         float* __restrict__ pooled) {
+  constexpr int E = PoolMma<T>::E;
+  constexpr int NG = PoolMma<T>::NG;
+  constexpr int A_CH = BOTT / E;                 // 16-byte chunks per a row   (16 bf16 / 32 f32)
+  constexpr int H_CH = PC / E;                   // chunks per h row slab      (32 / 64)
+  constexpr int A_BYTES = PT * BOTT * (int)sizeof(T);
+  constexpr int H_BYTES = PT * PC * (int)sizeof(T);
+  constexpr int A_PER = PT * A_CH / 512;         // chunks each thread stages  (1 / 2)
+  constexpr int H_PER = PT * H_CH / 512;         //                            (2 / 4)
+  typedef typename PoolMma<T>::Frag Frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x (a tile | h tile)
+
+  const int b = blockIdx.y;
+  const int s = row_off[b], n = row_off[b + 1] - s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int c_base = blockIdx.x * PC;
+  const int co = c_base + wv * 32 + fr;          // this lane's channel (W2 rows are padded to a multiple of 256)
+  const bool co_ok = co < ccat_p;
+
+  Frag wf[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) wf[g] = *(const Frag*)(w2 + (size_t)co * BOTT + (2 * g + fh) * E);
+
+  u32x4 areg[A_PER], hreg[H_PER];
+  auto load_tile = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t0 + row < n) v = *(const u32x4*)(a + (size_t)(s + t0 + row) * lda + ch * E);
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < H_PER; ++i) {
+      const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t0 + row < n && c_base + ch * E < ccat_p) v = *(const u32x4*)(h + (size_t)(s + t0 + row) * ldh + c_base + ch * E);
+      hreg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* ab = smem + buf * (A_BYTES + H_BYTES);
+    unsigned char* hb = ab + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
+      *(u32x4*)(ab + row * (A_CH * 16) + ((ch ^ (row & 15)) << 4)) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < H_PER; ++i) {
+      const int idx = tid + i * 512;
+      *(u32x4*)(hb + idx * 16) = hreg[i];          // plain [row][channel] image
+    }
+  };
+
+  float m = -1e30f, l = 0.f, s1 = 0.f, s2 = 0.f;
+  const int ntiles = (n + PT - 1) / PT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int it = 0; it < ntiles; ++it) {
+    const int t0 = it * PT;
+    const bool more = it + 1 < ntiles;
+    if (more) load_tile(t0 + PT);
+    const unsigned char* ab = smem + (it & 1) * (A_BYTES + H_BYTES);
+    const T* hs = (const T*)(ab + A_BYTES);
+    // logits tile [32 frames][32 channels]
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int ch = 2 * g + fh;
+      const Frag af = *(const Frag*)(ab + fr * (A_CH * 16) + ((ch ^ (fr & 15)) << 4));
+      PoolMma<T>::mma(acc, af, wf[g]);
+    }
+    float hv[16];
+    float tmax = -1e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+      const bool ok = t0 + row < n;
+      hv[e] = to_f32(hs[row * PC + wv * 32 + fr]);      // zero-filled past n / ccat_p
+      acc[e] = ok ? acc[e] : -1e30f;
+      tmax = fmaxf(tmax, acc[e]);
+    }
+    if (tmax > m) {
+      const float f = __expf(m - tmax);
+      l *= f; s1 *= f; s2 *= f;
+      m = tmax;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p = acc[e] > -1e29f ? __expf(acc[e] - m) : 0.f;
+      l += p;
+      const float ph = p * hv[e];
+      s1 += ph;
+      s2 = fmaf(ph, hv[e], s2);
+    }
+    if (more) store_tile((it + 1) & 1);
+    __syncthreads();
+  }
+  // merge the two half-waves (same channel, disjoint frames)
+  const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), s12 = __shfl_xor(s1, 32), s22 = __shfl_xor(s2, 32);
+  const float M = fmaxf(m, m2);
+  const float f1 = __expf(m - M), f2 = __expf(m2 - M);
+  l = l * f1 + l2 * f2;
+  s1 = s1 * f1 + s12 * f2;
+  s2 = s2 * f1 + s22 * f2;
+  if (fh == 0 && co_ok) {
+    const float mean = s1 / l;
+    const float var = s2 / l - mean * mean;
+    pooled[(size_t)b * 2 * ccat_p + co] = mean;
+    pooled[(size_t)b * 2 * ccat_p + ccat_p + co] = sqrtf(fmaxf(var, 1e-9f));
+  }
+}
+
+template <typename T>
+int launch_t(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh, const int32_t* d_row_off, int B,
+             float* d_pooled, hipStream_t s) {
+  const int smem = 2 * PT * (BOTT + PC) * (int)sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SUGAR_HIP(hipFuncSetAttribute((const void*)pool_stats_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)ceil_div(P.ccat_p, PC), (unsigned)B);
+  hipLaunchKernelGGL(pool_stats_kernel<T>, grid, dim3(512), smem, s, (const T*)d_a, lda, (const T*)d_h, ldh,
+                     (const T*)P.w2, P.ccat_p, d_row_off, d_pooled);
+  SUGAR_LAUNCH_CHECK();
+  return SUGAR_OK;
+}
+
+}  // namespace
+
+int launch_pool_stats(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh,
+                      const int32_t* d_row_off, int B, float* d_pooled, int dtype, hipStream_t s) {
+  const int E = dtype == SUGAR_F32 ? 4 : 8;
+  SUGAR_CHECK_ARG(P.bott == BOTT, "pool: bottleneck %d unsupported (reference fixes 128, dynamictdnn.py:494)", P.bott);
+  SUGAR_CHECK_ARG(lda % E == 0 && ldh % E == 0 && P.ccat_p % E == 0 && ((uintptr_t)d_a & 15) == 0 &&
+                      ((uintptr_t)d_h & 15) == 0,
+                  "pool: unaligned activations");
+  if (dtype == SUGAR_F32) return launch_t<float>(P, d_a, lda, d_h, ldh, d_row_off, B, d_pooled, s);
+  return launch_t<bf16>(P, d_a, lda, d_h, ldh, d_row_off, B, d_pooled, s);
+}
+
+}  // namespace sugar

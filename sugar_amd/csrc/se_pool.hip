@@ -4,11 +4,7 @@
 //                     frames -> Linear -> ReLU -> Linear -> sigmoid, one workgroup per utterance.
 //  se_apply_kernel  : the channel scale (:98-99) fused with the dense residual bookkeeping of
 //                     DynamicTDNN.forward (:657-660):  out = y * s + S ;  S = S + out.
-//  pool_stats_kernel: DynamicAttentiveStatsPool.forward (:505-515) after linear1+tanh: the linear2 GEMM
-//                     (K = 128) runs on MFMA with the accumulator laid out [frame][channel], so each lane owns one
-//                     channel and 16 frames of a 32-frame tile: softmax over time, sum(alpha h) and sum(alpha h^2)
-//                     are an in-lane online-softmax recurrence; logits and alpha are never written to memory and
-//                     h (the largest activation of the network) is read exactly once.
+//  (attentive statistics pooling lives in pool.hip)
 //  tail_kernel      : bnpool -> linear -> bnembed (:664-665) folded into one affine map at pack time.
 //  l2norm_kernel    : F.normalize(p=2, dim=1) (sugar/vectors.py:143-144).
 #include "common.h"
@@ -172,105 +168,6 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ y, 
   }
 }
 
-// ------------------------------------------------------------------------------------------ attentive stats
-template <typename T>
-struct PoolMma;
-template <>
-struct PoolMma<bf16> {
-  typedef bf16x8 Frag;
-  static constexpr int NG = 8;   // 128 / 16
-  __device__ __forceinline__ static void mma(f32x16& acc, const Frag& a, const Frag& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-  }
-};
-template <>
-struct PoolMma<float> {
-  typedef f32x4 Frag;
-  static constexpr int NG = 16;  // 128 / 8
-  __device__ __forceinline__ static void mma(f32x16& acc, const Frag& a, const Frag& b) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
-  }
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void pool_stats_kernel(const T* __restrict__ a, int lda, const T* __restrict__ h,
-                                                         int ldh, const T* __restrict__ w2, int ccat_p,
-                                                         const int32_t* __restrict__ row_off,
-                                                         float* __restrict__ pooled) {
-  constexpr int E = Chunk<T>::N;
-  constexpr int NG = PoolMma<T>::NG;
-  constexpr int BOTT = 128;
-  typedef typename PoolMma<T>::Frag Frag;
-  const int b = blockIdx.y;
-  const int s = row_off[b], n = row_off[b + 1] - s;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int co = blockIdx.x * 128 + wv * 32 + fr;          // this lane's channel (w2 rows are padded to 128)
-
-  Frag wf[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) wf[g] = *(const Frag*)(w2 + (size_t)co * BOTT + (2 * g + fh) * E);
-
-  const bool co_ok = co < ccat_p;
-  float m = -1e30f, l = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int t0 = 0; t0 < n; t0 += 32) {
-    // logits tile [32 frames][32 channels]: A = tanh(linear1) rows, B = linear2 weight rows
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int ar = t0 + fr;
-    const bool a_ok = ar < n;
-    const T* __restrict__ ap = a + (size_t)(s + (a_ok ? ar : 0)) * lda + fh * E;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      Frag af;
-      if (a_ok) af = *(const Frag*)(ap + 2 * g * E);
-      else {
-#pragma unroll
-        for (int i = 0; i < E; ++i) af[i] = (T)0.f;
-      }
-      PoolMma<T>::mma(acc, af, wf[g]);
-    }
-    float hv[16];
-    float tmax = -1e30f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = t0 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-      const bool ok = r < n && co_ok;
-      hv[e] = ok ? to_f32(h[(size_t)(s + r) * ldh + co]) : 0.f;
-      acc[e] = ok ? acc[e] : -1e30f;
-      tmax = fmaxf(tmax, acc[e]);
-    }
-    if (tmax > m) {
-      const float f = __expf(m - tmax);
-      l *= f; s1 *= f; s2 *= f;
-      m = tmax;
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float p = acc[e] > -1e29f ? __expf(acc[e] - m) : 0.f;
-      l += p;
-      const float ph = p * hv[e];
-      s1 += ph;
-      s2 = fmaf(ph, hv[e], s2);
-    }
-  }
-  // merge the two half-waves (same channel, disjoint frames)
-  const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), s12 = __shfl_xor(s1, 32), s22 = __shfl_xor(s2, 32);
-  const float M = fmaxf(m, m2);
-  const float f1 = __expf(m - M), f2 = __expf(m2 - M);
-  l = l * f1 + l2 * f2;
-  s1 = s1 * f1 + s12 * f2;
-  s2 = s2 * f1 + s22 * f2;
-  if (fh == 0 && co_ok) {
-    const float mean = s1 / l;
-    const float var = s2 / l - mean * mean;
-    pooled[(size_t)b * 2 * ccat_p + co] = mean;
-    pooled[(size_t)b * 2 * ccat_p + ccat_p + co] = sqrtf(fmaxf(var, 1e-9f));
-  }
-}
-
 // ------------------------------------------------------------------------------------------ tail
 constexpr int TAIL_U = 16;    // utterances per workgroup
 constexpr int TAIL_K = 512;   // pooled features per k-split
@@ -374,22 +271,6 @@ int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, voi
   else
     hipLaunchKernelGGL(se_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_y, ldy, d_scale, c_p,
                        (bf16*)d_S, ldS, (bf16*)d_out, ldo, write_S, d_row_off);
-  SUGAR_LAUNCH_CHECK();
-  return SUGAR_OK;
-}
-
-int launch_pool_stats(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh,
-                      const int32_t* d_row_off, int B, float* d_pooled, int dtype, hipStream_t s) {
-  const int E = dtype == SUGAR_F32 ? 4 : 8;
-  SUGAR_CHECK_ARG(P.bott == 128, "pool: bottleneck %d unsupported (reference fixes 128, dynamictdnn.py:494)", P.bott);
-  SUGAR_CHECK_ARG(lda % E == 0 && ((uintptr_t)d_a & 15) == 0, "pool: unaligned bottleneck activations");
-  const dim3 grid((unsigned)ceil_div(P.ccat_p, 128), (unsigned)B);
-  if (dtype == SUGAR_F32)
-    hipLaunchKernelGGL(pool_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)d_a, lda, (const float*)d_h,
-                       ldh, (const float*)P.w2, P.ccat_p, d_row_off, d_pooled);
-  else
-    hipLaunchKernelGGL(pool_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_a, lda, (const bf16*)d_h, ldh,
-                       (const bf16*)P.w2, P.ccat_p, d_row_off, d_pooled);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }

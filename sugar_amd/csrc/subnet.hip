@@ -189,7 +189,7 @@ static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
                       n->ccatp, nullptr, dtype)))
     return rc;
   {
-    const int rows = (int)round_up(n->ccatp, 128);
+    const int rows = (int)round_up(n->ccatp, 256);   // pool.hip: 256 channels per workgroup
     const size_t cnt = (size_t)rows * d->bottleneck;
     const size_t esz = dtype == SUGAR_F32 ? 4 : 2;
     std::vector<unsigned char> host(cnt * esz, 0);
