@@ -120,6 +120,11 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
               int cout_p, const int* out_map, int cin_p, const int* in_map, int dtype);
 void free_conv(ConvLayer* L);
 
+// ---- fused Res2 chain (res2.hip): all 7 sequential step convs of one block in one kernel ---------
+bool res2_chain_eligible(int dtype, int t_max, int wp, int k_pad, int n_pad);
+int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld, int wp, const int32_t* d_row_off,
+                      int B, int t_max, hipStream_t s);
+
 // ---- front-end (fbank.hip) ----------------------------------------------------------------------
 int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
                  int B, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s);

@@ -301,6 +301,9 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     if ((rc = tapcopy(1 + 4 * i, w.mid1, b.midp, b.midp))) return rc;
     {
     Prof p(SUGAR_STAGE_RES2, s);
+    if (res2_chain_eligible(dt, t_max, b.wp, b.res[0].k_pad, b.res[0].n_pad)) {   // whole chain in one kernel
+      if ((rc = launch_res2_chain(b.res, w.mid1, w.mid2, b.midp, b.wp, row_off, B, t_max, s))) return rc;
+    } else
     for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {                              // dynamictdnn.py:294-299
       ConvIO r;
       r.x = col(w.mid1, (int64_t)j * b.wp); r.ldx = b.midp;

@@ -214,3 +214,37 @@ def test_l2norm_matches_f_normalize():
     xd = x.to(DEV).clone()
     _lib.check(_lib.lib().sugar_l2norm(xd.data_ptr(), 33, 192, torch.cuda.current_stream().cuda_stream))
     assert (xd.cpu() - F.normalize(x, p=2, dim=1)).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ fused Res2 chain
+@pytest.mark.parametrize("name", ["base", "largest", "smallest", "odd", "rand0"])
+def test_fused_res2_chain_matches_per_step_path_bf16(name, meta, supernet):
+    """The one-kernel Res2 chain (res2.hip) against the 7-launch generic path, same bf16 inputs, ragged utterances."""
+    import os
+    cfg = cfg_of(meta, name)
+    sub = supernet.clone(cfg).set_precision("bf16")
+    supernet.config = None
+    frames = [301, 63, 17, 130]
+    R = sum(frames)
+    feats = synth.normal("res2/feats", (R, 80), seed=4).to(torch.bfloat16).to(DEV)
+    row_off = torch.tensor(_row_off(frames), dtype=torch.int32, device=DEV)
+    depth = cfg[0]
+    outs = {}
+    for mode in ("fused", "generic"):
+        if mode == "generic":
+            os.environ["SUGAR_GENERIC_RES2"] = "1"
+        try:
+            outs[mode] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
+            outs[mode].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
+        finally:
+            os.environ.pop("SUGAR_GENERIC_RES2", None)
+    for i in range(depth):
+        a, b = outs["fused"][i].float(), outs["generic"][i].float()
+        assert torch.isfinite(a).all()
+        # the fused chain adds x_j + sp_{j-1} before one bf16 rounding (the per-step path rounds sp first): the two
+        # differ by bf16 rounding noise propagated through <= 7 steps and i blocks, nothing larger
+        rel = ((a - b).norm() / b.norm()).item()
+        print(name, "block", i, "res2 rel L2 fused vs per-step %.2e" % rel)
+        assert rel < 1.5e-2, (name, i, rel)
+    cos = F.cosine_similarity(outs["fused"][-1].double(), outs["generic"][-1].double(), dim=1)
+    assert cos.min() > 0.9995
