@@ -127,12 +127,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < XROWS; ++i) {
       const int src = r_base + lr + 32 * i + roff;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (kvalid && src >= seg[i].x && src < seg[i].y) {
-        v = *(const u32x4*)(x + (size_t)src * a.ldx + ci);
-        if (x2) v = add_chunks<T>(v, *(const u32x4*)(x2 + (size_t)src * a.ldx2 + ci));
-      }
-      xreg[i] = v;
+      // unconditional loads from a clamped (always valid) row, then select: a branch around each load makes hipcc
+      // wait vmcnt(0) per element and serialises the tile's memory round trips
+      const bool ok = kvalid && src >= seg[i].x && src < seg[i].y;
+      const int srcc = max(min(src, seg[i].y - 1), seg[i].x);
+      u32x4 v = *(const u32x4*)(x + (size_t)srcc * a.ldx + ci);
+      if (x2) v = add_chunks<T>(v, *(const u32x4*)(x2 + (size_t)srcc * a.ldx2 + ci));
+      xreg[i] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
     }
   };
   auto store_tile = [&](int buf) {

@@ -74,16 +74,16 @@ __global__ __launch_bounds__(512) void pool_stats_kernel(const T* __restrict__ a
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (t0 + row < n) v = *(const u32x4*)(a + (size_t)(s + t0 + row) * lda + ch * E);
-      areg[i] = v;
+      // unconditional load from a clamped row, then select (no branch around the load: keeps the loads pipelined)
+      const u32x4 v = *(const u32x4*)(a + (size_t)(s + min(t0 + row, n - 1)) * lda + ch * E);
+      areg[i] = t0 + row < n ? v : (u32x4){0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int i = 0; i < H_PER; ++i) {
       const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (t0 + row < n && c_base + ch * E < ccat_p) v = *(const u32x4*)(h + (size_t)(s + t0 + row) * ldh + c_base + ch * E);
-      hreg[i] = v;
+      const int cc = min(c_base + ch * E, ccat_p - E);
+      const u32x4 v = *(const u32x4*)(h + (size_t)(s + min(t0 + row, n - 1)) * ldh + cc);
+      hreg[i] = (t0 + row < n && c_base + ch * E < ccat_p) ? v : (u32x4){0u, 0u, 0u, 0u};
     }
   };
   auto store_tile = [&](int buf) {
