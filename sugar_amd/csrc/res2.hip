@@ -10,9 +10,12 @@
 //     utterance's true ends), chunk-swizzled so the shifted fragment reads of every tap are bank-conflict free;
 //   * each wave owns up to 5 tiles of 16 frames; D[channel][frame] = sum over (tap, ci) W[co][tap*w+ci] u[frame+off][ci]
 //     with v_mfma_f32_16x16x32_bf16; the weights of step j+1 are prefetched into registers during step j and
-//     staged in LDS with the same XOR swizzle;
-//   * sp_j never round-trips through memory: the epilogue (ReLU -> folded BN) stores it to the output slice AND
-//     adds the prefetched x_{j+1} to form the next u in registers.
+//     staged in LDS with the same XOR swizzle; the folded-BN vectors of all 7 steps sit in LDS;
+//   * global traffic is row-contiguous, 16 bytes per lane: the MFMA epilogue (ReLU -> folded BN) drops sp_j of one
+//     frame tile into a wave-private 2 KB LDS tile, the wave reads it back as whole 16-byte chunks, stores them to the
+//     output slice and adds the x_{j+1} chunks (prefetched one step ahead in the same layout) to form u_{j+1}.
+//     In-kernel stamps showed the earlier 8-byte-per-lane loads/stores in MFMA layout (16 half-used lines per
+//     instruction, 37 vector-memory instructions per wave and step) spent 60 % of every step in memory issue.
 // Utterances longer than 640 frames (or f32) take the generic per-step path in conv_gemm.hip.
 #include <stdlib.h>
 
@@ -24,26 +27,54 @@ namespace {
 constexpr int R2_TPW_MAX = 5;        // frame tiles (of 16) per wave: 3 (T <= 384) or 5 (T <= 640)
 constexpr int R2_WAVES = 8;
 constexpr int R2_MAX_T = 16 * R2_TPW_MAX * R2_WAVES;   // 640 frames
+constexpr int R2_STEPS = SUGAR_RES2_SCALE - 1;
 
 struct Res2Args {
   const bf16* x;     // first_conv output [R][ld]
   bf16* y;           // Res2 output [R][ld] (groups 0..6 written here)
-  const bf16* w[SUGAR_RES2_SCALE - 1];        // packed [64][k_pad]
-  const float* scale[SUGAR_RES2_SCALE - 1];
-  const float* shift[SUGAR_RES2_SCALE - 1];
+  const bf16* w[R2_STEPS];        // packed [64][k_pad]
+  const float* scale[R2_STEPS];
+  const float* shift[R2_STEPS];
   const int32_t* row_off;
   int ld, wp, ktaps, dil, k_pad;
 };
 
-constexpr int R2_WREG = 5;           // 16-byte weight chunks each thread stages per step (k_pad <= 320)
+// Diagnostic build only (tools/res2_bench.hip defines R2_STAMPS): shader-clock stamps of wave 0 / wave 7 of two
+// workgroups go to a buffer of their own; the library build compiles none of this.
+#ifdef R2_STAMPS
+__device__ long long* g_r2_stamps;
+#define R2_STAMP()                                                                                      \
+  do {                                                                                                  \
+    if (stamp_on) { stamp_buf[stamp_n] = (long long)__builtin_amdgcn_s_memtime(); ++stamp_n; }          \
+  } while (0)
+#else
+#define R2_STAMP() do {} while (0)
+#endif
 
-template <int MT, int R2_TPW>
+__device__ __forceinline__ u32x4 add_bf16x8(u32x4 xa, u32x4 xb) {
+  // per element: bf16(f32(a) + f32(b)) -- the reference adds x_{j+1} + sp_j in f32 (dynamictdnn.py:298)
+  const bf16x8 a = __builtin_bit_cast(bf16x8, xa), b = __builtin_bit_cast(bf16x8, xb);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (bf16)((float)a[e] + (float)b[e]);
+  return __builtin_bit_cast(u32x4, r);
+}
+
+// WREG = 16-byte weight chunks each thread stages per step: 3 (k_pad <= 192) or 5 (k_pad <= 320)
+template <int MT, int R2_TPW, int WREG>
 __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NI = (MT + 1) / 2;                      // 16-byte chunk items per lane and frame tile
   const int b = blockIdx.x;
   const int s0 = a.row_off[b], T = a.row_off[b + 1] - s0;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int f = lane & 15, q = lane >> 4;
+#ifdef R2_STAMPS
+  const bool stamp_on = g_r2_stamps && lane == 0 && (wv == 0 || wv == 7) && (b == 0 || b == 200);
+  long long* stamp_buf = g_r2_stamps + ((b ? 2 : 0) + (wv ? 1 : 0)) * 64;
+  int stamp_n = 0;
+#endif
+  R2_STAMP();
   const int wp = a.wp, ctr = (a.ktaps - 1) >> 1, halo = ctr * a.dil;
   const int NT = (T + 15) >> 4;
   const int urow = wp * 2;                              // bytes per u row
@@ -55,84 +86,92 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   const int wchunks = a.k_pad >> 3;                     // chunks per weight row (multiple of 8)
   unsigned char* u = smem;
   unsigned char* wl = smem + u_bytes;
+  unsigned char* ob = wl + 64 * wstride + wv * (16 * urow);          // this wave's sp staging tile [16][wp]
+  float* ss = (float*)(wl + 64 * wstride + R2_WAVES * 16 * urow);    // [7][scale 64 | shift 64]
   const int nks = a.k_pad >> 5;                         // k-steps of 32
 
   // zero the whole u tile once: halo rows and frames >= T stay zero for the whole chain
   for (int i = tid; i < u_bytes / 16; i += 512) ((u32x4*)u)[i] = (u32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < R2_STEPS * 128; i += 512) {
+    const int j = i >> 7, c = i & 63;
+    ss[i] = (i & 64) ? a.shift[j][c] : a.scale[j][c];
+  }
 
   int ntw = 0;                                          // tiles owned by this wave: t = wv + 8 n
 #pragma unroll
   for (int n = 0; n < R2_TPW; ++n) ntw += (wv + R2_WAVES * n) < NT;
 
   // per-thread weight staging slots: chunk idx = tid + 512 i of the [64][wchunks] panel
-  int wsrc[R2_WREG], wdst[R2_WREG];
+  int wsrc[WREG], wdst[WREG];
 #pragma unroll
-  for (int i = 0; i < R2_WREG; ++i) {
+  for (int i = 0; i < WREG; ++i) {
     const int idx = tid + 512 * i;
     const int row = idx / wchunks, c = idx - row * wchunks;
     wsrc[i] = idx < 64 * wchunks ? row * a.k_pad + c * 8 : -1;
     wdst[i] = row * wstride + (((c & ~7) | ((c & 7) ^ (row & 7))) << 4);
   }
-  u32x4 wreg[R2_WREG];
+  u32x4 wreg[WREG];
   auto load_w = [&](int j) {
 #pragma unroll
-    for (int i = 0; i < R2_WREG; ++i) wreg[i] = *(const u32x4*)(a.w[j] + max(wsrc[i], 0));   // unconditional, see load_x
+    for (int i = 0; i < WREG; ++i) wreg[i] = *(const u32x4*)(a.w[j] + max(wsrc[i], 0));   // unconditional, see load_x
   };
   auto store_w = [&]() {
 #pragma unroll
-    for (int i = 0; i < R2_WREG; ++i)
+    for (int i = 0; i < WREG; ++i)
       if (wsrc[i] >= 0) *(u32x4*)(wl + wdst[i]) = wreg[i];
   };
-  // xu holds x_j on load and is turned in place into u_{j+1} = x_{j+1} + sp_j by the epilogue
-  bf16x4 xu[R2_TPW][MT];
+
+  // row-contiguous chunk items of a 16-frame tile: item = lane + 64 i -> (frame it / nch, chunk it % nch)
+  int irow[NI], ich[NI], ooff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int it = lane + 64 * i;
+    const int rl = it / nch;
+    irow[i] = rl < 16 ? rl : 16;                        // 16 = no such item
+    ich[i] = it - rl * nch;
+    ooff[i] = (rl & 15) * urow + ((ich[i] ^ (rl & swz_mask)) << 4);
+  }
+  const bf16* xb = a.x + (size_t)s0 * a.ld;
+  bf16* yb = a.y + (size_t)s0 * a.ld;
+  // xq holds x_j chunks on load and is turned in place into u_{j+1} = x_{j+1} + sp_j by the epilogue
+  u32x4 xq[R2_TPW][NI];
+  auto item_ok = [&](int n, int i) { return n < ntw && irow[i] < 16 && (wv + R2_WAVES * n) * 16 + irow[i] < T; };
   auto load_x = [&](int j) {
 #pragma unroll
-    for (int n = 0; n < R2_TPW; ++n) {
-      const int r = (wv + R2_WAVES * n) * 16 + f;
+    for (int n = 0; n < R2_TPW; ++n)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = m * 16 + 4 * q;
+      for (int i = 0; i < NI; ++i) {
         // unconditional load from a clamped (always valid) address, then select: a branch around each load would
-        // make hipcc wait vmcnt(0) per element and serialise 12 memory round trips per step
-        const bf16x4 v = *(const bf16x4*)(a.x + (size_t)(s0 + min(r, T - 1)) * a.ld + j * wp + min(ci, wp - 4));
-        const bool ok = n < ntw && r < T && ci < wp;
-        xu[n][m] = ok ? v : (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        // make hipcc wait vmcnt(0) per element and serialise the memory round trips
+        const int r = min((wv + R2_WAVES * n) * 16 + min(irow[i], 15), T - 1);
+        const u32x4 v = *(const u32x4*)(xb + r * a.ld + j * wp + ich[i] * 8);
+        xq[n][i] = item_ok(n, i) ? v : (u32x4){0u, 0u, 0u, 0u};
       }
-    }
   };
   auto write_u = [&]() {
 #pragma unroll
-    for (int n = 0; n < R2_TPW; ++n) {
-      const int r = (wv + R2_WAVES * n) * 16 + f;
-      const int row = r + halo;
+    for (int n = 0; n < R2_TPW; ++n)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = m * 16 + 4 * q;
-        if (n < ntw && r < T && ci < wp)
-          *(bf16x4*)(u + row * urow + (((ci >> 3) ^ (row & swz_mask)) << 4) + (ci & 7) * 2) = xu[n][m];
-      }
-    }
+      for (int i = 0; i < NI; ++i)
+        if (item_ok(n, i)) {
+          const int row = (wv + R2_WAVES * n) * 16 + irow[i] + halo;
+          *(u32x4*)(u + row * urow + ((ich[i] ^ (row & swz_mask)) << 4)) = xq[n][i];
+        }
   };
 
   load_w(0);
   load_x(0);                                            // u_0 = x_0
   __syncthreads();                                      // zero fill complete before the first u write
-  for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {
-    const bool last = j + 1 == SUGAR_RES2_SCALE - 1;
-    write_u();
-    store_w();
-    // LDS-only barriers: waves exchange data through LDS alone, so only the LDS counter is drained; a full
-    // __syncthreads() would also wait (vmcnt(0)) for this step's output stores and the prefetches in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  R2_STAMP();
+  write_u();
+  store_w();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int j = 0; j < R2_STEPS; ++j) {
+    const bool last = j + 1 == R2_STEPS;
+    R2_STAMP();
     if (!last) {                                        // both in flight during the MFMA loop
       load_w(j + 1);
       load_x(j + 1);
-    }
-    f32x4 sc[MT], sh[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      sc[m] = *(const f32x4*)(a.scale[j] + m * 16 + 4 * q);
-      sh[m] = *(const f32x4*)(a.shift[j] + m * 16 + 4 * q);
     }
 
     f32x4 acc[R2_TPW][MT];
@@ -140,55 +179,104 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
     for (int n = 0; n < R2_TPW; ++n)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    R2_STAMP();
 
+    // K loop, fragments of k-step ks+1 read while the MFMAs of ks run (nks is even: k_pad % 64 == 0).  Tiles past
+    // ntw read a clamped (valid) row and their MFMAs are skipped.
     int tap = (q * 8) / wp, ci = q * 8 - tap * wp;      // this lane's K chunk c = 4 ks + q, walked incrementally
-    for (int ks = 0; ks < nks; ++ks) {
-      const int c = 4 * ks + q;
-      const bool kpad = tap >= a.ktaps;                 // K padding: weights are zero, read any valid row
+    int ks_ld = 0;
+    auto load_frags = [&](bf16x8 (&af)[MT], bf16x8 (&bf)[R2_TPW]) {
+      const int c = 4 * ks_ld + q;
+      const bool kpad = tap >= a.ktaps || ks_ld >= nks; // K padding: weights are zero, read any valid row
       const int roff = halo + (kpad ? 0 : (tap - ctr) * a.dil);
       const int cch = kpad ? 0 : (ci >> 3);
-      bf16x8 af[MT];
+      const int cw = ks_ld < nks ? c : q;               // one step past the end: any valid chunk, never consumed
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        af[m] = *(const bf16x8*)(wl + (m * 16 + f) * wstride + (((c & ~7) | ((c & 7) ^ (f & 7))) << 4));
+        af[m] = *(const bf16x8*)(wl + (m * 16 + f) * wstride + (((cw & ~7) | ((cw & 7) ^ (f & 7))) << 4));
 #pragma unroll
       for (int n = 0; n < R2_TPW; ++n) {
-        if (n < ntw) {
-          const int row = (wv + R2_WAVES * n) * 16 + f + roff;
-          const bf16x8 bf = *(const bf16x8*)(u + row * urow + ((cch ^ (row & swz_mask)) << 4));
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf, acc[n][m], 0, 0, 0);
-        }
+        const int row = (n < ntw ? (wv + R2_WAVES * n) * 16 : 0) + f + roff;
+        bf[n] = *(const bf16x8*)(u + row * urow + ((cch ^ (row & swz_mask)) << 4));
       }
       ci += 32;
       while (ci >= wp) { ci -= wp; ++tap; }
-    }
-
-    // epilogue: lane (f, q) holds frame t*16 + f, channels m*16 + 4q + {0..3}
+      ++ks_ld;
+    };
+    auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[R2_TPW]) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int co = m * 16 + 4 * q;
-#pragma unroll
-      for (int n = 0; n < R2_TPW; ++n) {
+      for (int n = 0; n < R2_TPW; ++n)
         if (n < ntw) {
-          const int r = (wv + R2_WAVES * n) * 16 + f;
-          f32x4 v = acc[n][m];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-          v = v * sc[m] + sh[m];
-          const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          if (r < T && co < wp) *(bf16x4*)(a.y + (size_t)(s0 + r) * a.ld + j * wp + co) = o;
-          if (!last) {
-            // next conv input: x_{j+1} + sp_j (the reference adds in f32, dynamictdnn.py:298)
-            const bf16x4 xv = xu[n][m];
-            xu[n][m] = (bf16x4){(bf16)((float)xv[0] + v[0]), (bf16)((float)xv[1] + v[1]), (bf16)((float)xv[2] + v[2]),
-                                (bf16)((float)xv[3] + v[3])};
-          }
+          for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[n][m], 0, 0, 0);
         }
+    };
+    {
+      bf16x8 af0[MT], bf0[R2_TPW], af1[MT], bf1[R2_TPW];
+      load_frags(af0, bf0);
+      for (int ks = 0; ks < nks; ks += 2) {
+        load_frags(af1, bf1);
+        mma(af0, bf0);
+        load_frags(af0, bf0);
+        mma(af1, bf1);
       }
     }
+    R2_STAMP();
+
+    // epilogue, one frame tile at a time: lane (f, q) holds frame f, channels m*16 + 4q + {0..3} -> wave-private LDS
+    // tile -> whole 16-byte chunks.  LDS executes one wave's instructions in order, so the tile is reused without
+    // waiting; the wave barriers only pin the compiler's order.
+    f32x4 sc[MT], sh[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      sc[m] = *(const f32x4*)(ss + j * 128 + m * 16 + 4 * q);
+      sh[m] = *(const f32x4*)(ss + j * 128 + 64 + m * 16 + 4 * q);
+    }
+#pragma unroll
+    for (int n = 0; n < R2_TPW; ++n) {
+      if (n < ntw) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int co = m * 16 + 4 * q;
+          f32x4 v = acc[n][m];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          v = v * sc[m] + sh[m];
+          const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          if (co < wp) *(bf16x4*)(ob + f * urow + (((co >> 3) ^ (f & swz_mask)) << 4) + (co & 7) * 2) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const u32x4 sp = *(const u32x4*)(ob + ooff[i]);
+          if (item_ok(n, i)) {
+            const int r = (wv + R2_WAVES * n) * 16 + irow[i];
+            *(u32x4*)(yb + r * a.ld + j * wp + ich[i] * 8) = sp;
+            if (!last) xq[n][i] = add_bf16x8(xq[n][i], sp);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    R2_STAMP();
+    // LDS-only barriers: waves exchange data through LDS alone, so only the LDS counter is drained; a full
+    // __syncthreads() would also wait (vmcnt(0)) for this step's output stores and the prefetches in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves done reading u and the weights
+    R2_STAMP();
+    if (!last) {
+      write_u();
+      store_w();
+    }
+    R2_STAMP();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+}
+
+int r2_smem_bytes(int t_max, int wp, int halo, int k_pad) {
+  const int u_rows = (t_max + 15) / 16 * 16 + 2 * halo;
+  return ((u_rows * wp * 2 + 255) & ~255) + 64 * k_pad * 2 + R2_WAVES * 16 * wp * 2 + R2_STEPS * 128 * 4;
 }
 
 }  // namespace
@@ -196,8 +284,7 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
 bool res2_chain_eligible(int dtype, int t_max, int wp, int k_pad, int n_pad) {
   if (dtype != SUGAR_BF16 || t_max > R2_MAX_T || wp > 64 || wp % 8 != 0 || n_pad != 64) return false;
   if (getenv("SUGAR_GENERIC_RES2")) return false;   // A/B switch for the parity tests: force the per-step path
-  const int u_bytes = ((t_max + 15) / 16 * 16 + 2 * 10) * wp * 2 + 256;
-  return k_pad <= 64 * R2_WREG && u_bytes + 64 * k_pad * 2 <= 160 * 1024;
+  return k_pad <= 64 * 5 && r2_smem_bytes(t_max, wp, 10, k_pad) <= 160 * 1024;
 }
 
 int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld, int wp, const int32_t* d_row_off,
@@ -205,36 +292,42 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   Res2Args a;
   a.x = (const bf16*)d_x; a.y = (bf16*)d_y; a.row_off = d_row_off;
   a.ld = ld; a.wp = wp; a.ktaps = steps[0].ktaps; a.dil = steps[0].dil; a.k_pad = steps[0].k_pad;
-  for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {
+  for (int j = 0; j < R2_STEPS; ++j) {
     SUGAR_CHECK_ARG(steps[j].k_pad == a.k_pad && steps[j].ktaps == a.ktaps && steps[j].scale && steps[j].n_pad == 64,
                     "res2: inconsistent step %d", j);
     a.w[j] = (const bf16*)steps[j].w; a.scale[j] = steps[j].scale; a.shift[j] = steps[j].shift;
   }
   const int halo = ((a.ktaps - 1) / 2) * a.dil;
-  const int u_rows = (t_max + 15) / 16 * 16 + 2 * halo;
-  const int smem = ((u_rows * wp * 2 + 255) & ~255) + 64 * a.k_pad * 2;
+  SUGAR_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && (int64_t)t_max * ld < (1ll << 31),
+                  "res2: activations must be 16-byte aligned with ld %% 8 == 0 (ld %d)", ld);
+  const int smem = r2_smem_bytes(t_max, wp, halo, a.k_pad);
+  SUGAR_CHECK_ARG(smem <= 160 * 1024 && a.k_pad <= 320, "res2: tile does not fit LDS (%d bytes)", smem);
   const int mt = (wp + 15) / 16;
   const bool small = t_max <= 16 * 3 * R2_WAVES;        // 3 frame tiles per wave cover 384 frames
-#define R2_CASE(M, TP)                                                                                         \
+  const bool w3 = a.k_pad <= 192;
+#define R2_CASE(M, TP, WR)                                                                                     \
   {                                                                                                            \
     static bool attr_set = false;                                                                              \
     if (!attr_set) {                                                                                           \
-      SUGAR_HIP(hipFuncSetAttribute((const void*)res2_chain_kernel<M, TP>,                                     \
+      SUGAR_HIP(hipFuncSetAttribute((const void*)res2_chain_kernel<M, TP, WR>,                                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((res2_chain_kernel<M, TP>), dim3(B), dim3(512), smem, s, a);                            \
+    hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR>), dim3(B), dim3(512), smem, s, a);                        \
   }
+#define R2_CASE_W(M, TP) \
+  if (w3) R2_CASE(M, TP, 3) else R2_CASE(M, TP, 5)
   switch (mt * 2 + (small ? 0 : 1)) {
-    case 2: R2_CASE(1, 3) break;
-    case 3: R2_CASE(1, 5) break;
-    case 4: R2_CASE(2, 3) break;
-    case 5: R2_CASE(2, 5) break;
-    case 6: R2_CASE(3, 3) break;
-    case 7: R2_CASE(3, 5) break;
-    case 8: R2_CASE(4, 3) break;
-    default: R2_CASE(4, 5) break;
+    case 2: R2_CASE_W(1, 3) break;
+    case 3: R2_CASE_W(1, 5) break;
+    case 4: R2_CASE_W(2, 3) break;
+    case 5: R2_CASE_W(2, 5) break;
+    case 6: R2_CASE_W(3, 3) break;
+    case 7: R2_CASE_W(3, 5) break;
+    case 8: R2_CASE_W(4, 3) break;
+    default: R2_CASE_W(4, 5) break;
   }
+#undef R2_CASE_W
 #undef R2_CASE
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
