@@ -172,8 +172,9 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "frames_per_utt": T,
                        "parallelism": "utterance-sharded x%d, all-gather of embeddings" % world,
                        "weights": "deterministic synthetic (sugar_amd/synth.py)"},
-            "roofline": {"kernel": "conv_gemm_kernel<%s,128,128> catconv launch [%d frames x K %d -> %d]"
-                                   % (args.precision, R, depth * ch[0], ccat),
+            "roofline": {"kernel": "%s catconv launch [%d frames x K %d -> %d]"
+                                   % ("gemm1x1_kernel (256x256x64 LDS-DMA MFMA GEMM)" if args.precision == "bf16"
+                                      else "conv_gemm_kernel<float,128,128>", R, depth * ch[0], ccat),
                          "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None,
                          "traffic": traffic, "launches_timed": n_cat,

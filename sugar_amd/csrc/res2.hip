@@ -86,8 +86,9 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   const int wchunks = a.k_pad >> 3;                     // chunks per weight row (multiple of 8)
   unsigned char* u = smem;
   unsigned char* wl = smem + u_bytes;
-  unsigned char* ob = wl + 64 * wstride + wv * (16 * urow);          // this wave's sp staging tile [16][wp]
-  float* ss = (float*)(wl + 64 * wstride + R2_WAVES * 16 * urow);    // [7][scale 64 | shift 64]
+  constexpr int OT = R2_TPW <= 3 ? R2_TPW : 1;          // sp staging tiles per wave
+  unsigned char* ob = wl + 64 * wstride + wv * (OT * 16 * urow);        // this wave's sp staging tiles [16][wp]
+  float* ss = (float*)(wl + 64 * wstride + R2_WAVES * OT * 16 * urow);  // [7][scale 64 | shift 64]
   const int nks = a.k_pad >> 5;                         // k-steps of 32
 
   // zero the whole u tile once: halo rows and frames >= T stay zero for the whole chain
@@ -133,10 +134,13 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   }
   const bf16* xb = a.x + (size_t)s0 * a.ld;
   bf16* yb = a.y + (size_t)s0 * a.ld;
-  // xq holds x_j chunks on load and is turned in place into u_{j+1} = x_{j+1} + sp_j by the epilogue
-  u32x4 xq[R2_TPW][NI];
+  // xs[(j+1)&1] holds the x_{j+1} chunks during step j and is turned in place into u_{j+1} = x_{j+1} + sp_j by the
+  // epilogue.  With <= 3 tiles per wave the registers allow loading TWO steps ahead (x_{j+2} during step j): the
+  // stamps showed a one-step prefetch still exposed ~2 us of memory latency per step, with every CU bursting at once.
+  constexpr bool DEEP = R2_TPW <= 3;
+  u32x4 xs[2][R2_TPW][NI];
   auto item_ok = [&](int n, int i) { return n < ntw && irow[i] < 16 && (wv + R2_WAVES * n) * 16 + irow[i] < T; };
-  auto load_x = [&](int j) {
+  auto load_x = [&](int j, int buf) {
 #pragma unroll
     for (int n = 0; n < R2_TPW; ++n)
 #pragma unroll
@@ -144,34 +148,38 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
         // unconditional load from a clamped (always valid) address, then select: a branch around each load would
         // make hipcc wait vmcnt(0) per element and serialise the memory round trips
         const int r = min((wv + R2_WAVES * n) * 16 + min(irow[i], 15), T - 1);
-        const u32x4 v = *(const u32x4*)(xb + r * a.ld + j * wp + ich[i] * 8);
-        xq[n][i] = item_ok(n, i) ? v : (u32x4){0u, 0u, 0u, 0u};
+        xs[buf][n][i] = *(const u32x4*)(xb + r * a.ld + j * wp + ich[i] * 8);   // items not item_ok are never used
       }
   };
-  auto write_u = [&]() {
+  auto write_u = [&](int buf) {
 #pragma unroll
     for (int n = 0; n < R2_TPW; ++n)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
         if (item_ok(n, i)) {
           const int row = (wv + R2_WAVES * n) * 16 + irow[i] + halo;
-          *(u32x4*)(u + row * urow + ((ich[i] ^ (row & swz_mask)) << 4)) = xq[n][i];
+          *(u32x4*)(u + row * urow + ((ich[i] ^ (row & swz_mask)) << 4)) = xs[buf][n][i];
         }
   };
 
+  const int inv_wp = (65536 + wp - 1) / wp;
   load_w(0);
-  load_x(0);                                            // u_0 = x_0
+  load_x(0, 0);                                         // u_0 = x_0
+  if (DEEP) load_x(1, 1);
   __syncthreads();                                      // zero fill complete before the first u write
   R2_STAMP();
-  write_u();
+  write_u(0);
   store_w();
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  for (int j = 0; j < R2_STEPS; ++j) {
+#pragma unroll
+  for (int j = 0; j < R2_STEPS; ++j) {                  // fully unrolled: the xs buffer index is static
     const bool last = j + 1 == R2_STEPS;
     R2_STAMP();
-    if (!last) {                                        // both in flight during the MFMA loop
-      load_w(j + 1);
-      load_x(j + 1);
+    if (!last) load_w(j + 1);                           // in flight during the MFMA loop
+    if (DEEP) {
+      if (j + 2 < R2_STEPS) load_x(j + 2, j & 1);
+    } else if (!last) {
+      load_x(j + 1, (j + 1) & 1);
     }
 
     f32x4 acc[R2_TPW][MT];
@@ -183,10 +191,10 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
 
     // K loop, fragments of k-step ks+1 read while the MFMAs of ks run (nks is even: k_pad % 64 == 0).  Tiles past
     // ntw read a clamped (valid) row and their MFMAs are skipped.
-    int tap = (q * 8) / wp, ci = q * 8 - tap * wp;      // this lane's K chunk c = 4 ks + q, walked incrementally
     int ks_ld = 0;
     auto load_frags = [&](bf16x8 (&af)[MT], bf16x8 (&bf)[R2_TPW]) {
-      const int c = 4 * ks_ld + q;
+      const int c = 4 * ks_ld + q;                      // this lane's K chunk
+      const int tap = (c * 8 * inv_wp) >> 16, ci = c * 8 - tap * wp;   // == c*8 / wp, % wp  (c*8 < 1024)
       const bool kpad = tap >= a.ktaps || ks_ld >= nks; // K padding: weights are zero, read any valid row
       const int roff = halo + (kpad ? 0 : (tap - ctr) * a.dil);
       const int cch = kpad ? 0 : (ci >> 3);
@@ -199,8 +207,6 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
         const int row = (n < ntw ? (wv + R2_WAVES * n) * 16 : 0) + f + roff;
         bf[n] = *(const bf16x8*)(u + row * urow + ((cch ^ (row & swz_mask)) << 4));
       }
-      ci += 32;
-      while (ci >= wp) { ci -= wp; ++tap; }
       ++ks_ld;
     };
     auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[R2_TPW]) {
@@ -232,32 +238,53 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
       sc[m] = *(const f32x4*)(ss + j * 128 + m * 16 + 4 * q);
       sh[m] = *(const f32x4*)(ss + j * 128 + 64 + m * 16 + 4 * q);
     }
+    auto stage_sp = [&](int n) {
+      unsigned char* ot = ob + (OT > 1 ? n : 0) * (16 * urow);
 #pragma unroll
-    for (int n = 0; n < R2_TPW; ++n) {
-      if (n < ntw) {
+      for (int m = 0; m < MT; ++m) {
+        const int co = m * 16 + 4 * q;
+        f32x4 v = acc[n][m];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int co = m * 16 + 4 * q;
-          f32x4 v = acc[n][m];
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        v = v * sc[m] + sh[m];
+        const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        if (co < wp) *(bf16x4*)(ot + f * urow + (((co >> 3) ^ (f & swz_mask)) << 4) + (co & 7) * 2) = o;
+      }
+    };
+    auto drain_sp = [&](int n) {
+      const unsigned char* ot = ob + (OT > 1 ? n : 0) * (16 * urow);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          v = v * sc[m] + sh[m];
-          const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          if (co < wp) *(bf16x4*)(ob + f * urow + (((co >> 3) ^ (f & swz_mask)) << 4) + (co & 7) * 2) = o;
+      for (int i = 0; i < NI; ++i) {
+        const u32x4 sp = *(const u32x4*)(ot + ooff[i]);
+        if (item_ok(n, i)) {
+          const int r = (wv + R2_WAVES * n) * 16 + irow[i];
+          *(u32x4*)(yb + r * a.ld + j * wp + ich[i] * 8) = sp;
+          if (!last) xs[(j + 1) & 1][n][i] = add_bf16x8(xs[(j + 1) & 1][n][i], sp);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    if (OT > 1) {                                       // a staging tile per frame tile: one LDS round trip per step
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const u32x4 sp = *(const u32x4*)(ob + ooff[i]);
-          if (item_ok(n, i)) {
-            const int r = (wv + R2_WAVES * n) * 16 + irow[i];
-            *(u32x4*)(yb + r * a.ld + j * wp + ich[i] * 8) = sp;
-            if (!last) xq[n][i] = add_bf16x8(xq[n][i], sp);
-          }
+      for (int n = 0; n < R2_TPW; ++n)
+        if (n < ntw) stage_sp(n);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int n = 0; n < R2_TPW; ++n)
+        if (n < ntw) drain_sp(n);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int n = 0; n < R2_TPW; ++n) {
+        if (n < ntw) {
+          stage_sp(n);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          drain_sp(n);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
     }
     R2_STAMP();
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves done reading u and the weights
     R2_STAMP();
     if (!last) {
-      write_u();
+      write_u((j + 1) & 1);
       store_w();
     }
     R2_STAMP();
@@ -276,7 +303,8 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
 
 int r2_smem_bytes(int t_max, int wp, int halo, int k_pad) {
   const int u_rows = (t_max + 15) / 16 * 16 + 2 * halo;
-  return ((u_rows * wp * 2 + 255) & ~255) + 64 * k_pad * 2 + R2_WAVES * 16 * wp * 2 + R2_STEPS * 128 * 4;
+  const int ot = t_max <= 16 * 3 * R2_WAVES ? 3 : 1;    // sp staging tiles per wave (kernel: OT)
+  return ((u_rows * wp * 2 + 255) & ~255) + 64 * k_pad * 2 + R2_WAVES * ot * 16 * wp * 2 + R2_STEPS * 128 * 4;
 }
 
 }  // namespace
