@@ -138,13 +138,25 @@ __global__ __launch_bounds__(256) void fbank_fft_kernel(const float* __restrict_
   // ---- stage pre-emphasised, reflect-padded samples + the mel weights ------------------------------
   const int base = t0 * HOP - WIN / 2;               // original index of buffer position 0 (= t0*160 - 256 + 56)
   const int span = (nf - 1) * HOP + WIN;
-  for (int p = tid; p < span; p += 256) {
+  // all 2 x 21 loads of a thread are issued before the first use: a rolled loop here paid one HBM round trip per
+  // iteration and was 3/4 of the kernel's time
+  constexpr int NSTG = (SPAN + 255) / 256;
+  float xc[NSTG], xp[NSTG];
+#pragma unroll
+  for (int i = 0; i < NSTG; ++i) {
+    const int p = min(tid + 256 * i, span - 1);
     int idx = base + p;
     if (idx < 0) idx = -idx;                         // reflect (torch.stft center=True, pad_mode="reflect")
     if (idx >= L) idx = 2 * (L - 1) - idx;
     idx = min(max(idx, 0), L - 1);
     const int prev = idx > 0 ? idx - 1 : 1;          // PreEmphasis reflect pad (1, 0): x[-1] := x[1]
-    samples[p] = x[idx] - 0.97f * x[min(prev, L - 1)];
+    xc[i] = x[idx];
+    xp[i] = x[min(prev, L - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < NSTG; ++i) {
+    const int p = tid + 256 * i;
+    if (p < span) samples[p] = xc[i] - 0.97f * xp[i];
   }
 
   // ---- per-lane constants: window taps, twiddles of passes 1..3, W512^k of the real-FFT split -------
@@ -161,14 +173,21 @@ __global__ __launch_bounds__(256) void fbank_fft_kernel(const float* __restrict_
 #pragma unroll
   for (int t = 0; t < 4; ++t) twp[t] = tb.tw[j + 64 * t];
   const int mel0 = j, mel1 = 64 + j;                 // lanes 0..15 own a second mel bin
-  const int lo0 = tb.mel_lo[mel0], cnt0 = tb.mel_cnt[mel0];
-  const int lo1 = j < NMEL - 64 ? tb.mel_lo[mel1] : 0, cnt1 = j < NMEL - 64 ? tb.mel_cnt[mel1] : 0;
+  const int lo0 = tb.mel_lo[mel0];
+  const int lo1 = j < NMEL - 64 ? tb.mel_lo[mel1] : 0;
+  // mel filter taps in registers (rows are zero-padded to MEL_MAXW): the projection below is 2 x 20 independent LDS
+  // reads per frame instead of a data-dependent loop of global loads
+  float mw0[MEL_MAXW], mw1[MEL_MAXW];
+#pragma unroll
+  for (int i = 0; i < MEL_MAXW; ++i) {
+    mw0[i] = tb.mel_w[mel0 * MEL_MAXW + i];
+    mw1[i] = j < NMEL - 64 ? tb.mel_w[mel1 * MEL_MAXW + i] : 0.f;
+  }
   __syncthreads();
 
   float2* A = fbuf[wv];
   float2* Bf = fbuf[wv];
   float* pw = (float*)fbuf[wv];
-  const float* __restrict__ melw = tb.mel_w;
   for (int f = wv; f < nf; f += 4) {
     const float2* sp = (const float2*)(samples + f * HOP);    // 160 f floats: 8-byte aligned
     float2 v0, v1, v2, v3;
@@ -230,14 +249,14 @@ __global__ __launch_bounds__(256) void fbank_fft_kernel(const float* __restrict_
     __builtin_amdgcn_wave_barrier();
     // sparse mel projection + log
     {
-      float s = 0.f;
-      for (int i = 0; i < cnt0; ++i) s = fmaf(pw[lo0 + i], melw[mel0 * MEL_MAXW + i], s);
-      tile[f * SLD + mel0] = logf(s + 1e-6f);
-      if (j < NMEL - 64) {
-        float s2 = 0.f;
-        for (int i = 0; i < cnt1; ++i) s2 = fmaf(pw[lo1 + i], melw[mel1 * MEL_MAXW + i], s2);
-        tile[f * SLD + mel1] = logf(s2 + 1e-6f);
+      float s = 0.f, s2 = 0.f;                           // taps past a filter's end have zero weight
+#pragma unroll
+      for (int i = 0; i < MEL_MAXW; ++i) {
+        s = fmaf(pw[min(lo0 + i, NBIN - 1)], mw0[i], s);
+        s2 = fmaf(pw[min(lo1 + i, NBIN - 1)], mw1[i], s2);
       }
+      tile[f * SLD + mel0] = logf(s + 1e-6f);
+      if (j < NMEL - 64) tile[f * SLD + mel1] = logf(s2 + 1e-6f);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -247,6 +266,7 @@ __global__ __launch_bounds__(256) void fbank_fft_kernel(const float* __restrict_
 }
 
 constexpr int NORM_LANES = 8;   // row lanes per mel bin
+constexpr int NORM_CACHE = 40;  // rows per lane kept in registers
 
 template <typename T>
 __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float* __restrict__ logmel,
@@ -257,8 +277,18 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float*
   const int s = row_off[b], n = row_off[b + 1] - s;
   const int m = threadIdx.x % NMEL, rl = threadIdx.x / NMEL;
   const float* __restrict__ src = logmel + (size_t)s * NMEL + m;
+  // the first NORM_CACHE rows of every row lane stay in registers (all loads in flight at once; utterances up to
+  // NORM_LANES * NORM_CACHE = 320 frames are read exactly once); longer ones re-read the remainder
+  float vals[NORM_CACHE];
   float acc = 0.f;
-  for (int r = rl; r < n; r += NORM_LANES) acc += src[(size_t)r * NMEL];
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) {
+    const int r = rl + NORM_LANES * i;
+    vals[i] = src[(size_t)min(r, n - 1) * NMEL];
+  }
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) acc += (rl + NORM_LANES * i < n) ? vals[i] : 0.f;
+  for (int r = rl + NORM_LANES * NORM_CACHE; r < n; r += NORM_LANES) acc += src[(size_t)r * NMEL];
   red[rl][m] = acc;
   __syncthreads();
   float mean = 0.f;
@@ -267,7 +297,12 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float*
   mean /= (float)n;
   __syncthreads();
   acc = 0.f;
-  for (int r = rl; r < n; r += NORM_LANES) {
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) {
+    const float d = (rl + NORM_LANES * i < n) ? vals[i] - mean : 0.f;
+    acc = fmaf(d, d, acc);
+  }
+  for (int r = rl + NORM_LANES * NORM_CACHE; r < n; r += NORM_LANES) {
     const float d = src[(size_t)r * NMEL] - mean;
     acc = fmaf(d, d, acc);
   }
@@ -279,7 +314,13 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float*
   var /= (float)n;                                     // biased, as InstanceNorm1d
   const float inv = 1.0f / sqrtf(var + 1e-5f);
   T* __restrict__ dst = feats + (size_t)s * NMEL + m;
-  for (int r = rl; r < n; r += NORM_LANES) dst[(size_t)r * NMEL] = from_f32<T>((src[(size_t)r * NMEL] - mean) * inv);
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) {
+    const int r = rl + NORM_LANES * i;
+    if (r < n) dst[(size_t)r * NMEL] = from_f32<T>((vals[i] - mean) * inv);
+  }
+  for (int r = rl + NORM_LANES * NORM_CACHE; r < n; r += NORM_LANES)
+    dst[(size_t)r * NMEL] = from_f32<T>((src[(size_t)r * NMEL] - mean) * inv);
 }
 }  // namespace
 
