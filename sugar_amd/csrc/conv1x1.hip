@@ -48,8 +48,9 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
 }
 
+// One TM x TN output tile at (co_base, r_base), by the whole 512-thread workgroup.
 template <int TM, int TN, int NS>
-__global__ __launch_bounds__(512, TM == 256 ? 2 : 4) void gemm1x1_kernel(Gemm1x1Args a) {
+__device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_base, const int r_base) {
   constexpr int STAGE_BYTES = (TM + TN) * 128;
   constexpr int MI = TM / 32;                    // 16-channel MFMA tiles per wave
   constexpr int NJ = TN / 64;                    // 16-frame MFMA tiles per wave
@@ -62,9 +63,6 @@ __global__ __launch_bounds__(512, TM == 256 ? 2 : 4) void gemm1x1_kernel(Gemm1x1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 2, wn = wv & 3;
-  const int vid = xcd_remap2(blockIdx.x, gridDim.x);
-  const int co_base = (vid % a.n_co_tiles) * TM;
-  const int r_base = (vid / a.n_co_tiles) * TN;
 
   // ---- DMA addressing: each wave fills its rows of both operand tiles, 8 rows (1 KiB) per instruction ----------
   const int srow = lane >> 3;                       // row within the 8-row slab
@@ -187,6 +185,35 @@ __global__ __launch_bounds__(512, TM == 256 ? 2 : 4) void gemm1x1_kernel(Gemm1x1
   }
 }
 
+// Uniform grid: every workgroup one TM x TN tile.
+template <int TM, int TN, int NS>
+__global__ __launch_bounds__(512, TM == 256 ? 2 : 4) void gemm1x1_kernel(Gemm1x1Args a) {
+  const int vid = xcd_remap2(blockIdx.x, gridDim.x);
+  gemm_tile<TM, TN, NS>(a, (vid % a.n_co_tiles) * TM, (vid / a.n_co_tiles) * TN);
+}
+
+// Split-tail grid for the wide convs.  With one 256 x 256 tile per CU at a time the makespan is ceil(tiles / CUs)
+// rounds, and the last round is often nearly empty (512-channel convs on 256 x 301 frames: 602 tiles = 2.35 rounds;
+// catconv: 1806 = 7.05).  The first n_main tiles (whole rounds) run as 256 x 256; each tile of the remainder is cut
+// along the frames into `split` (1, 2 or 4) sub-tiles with their own wave tiling, so the last round fills the chip
+// with pieces that take 1/2 or 1/4 of a round.  Same outputs bit for bit: every output element still sums its K
+// products in the same order.
+template <int NS>
+__global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, int n_main, int split) {
+  const int bid = blockIdx.x;
+  if (bid < n_main) {
+    const int vid = xcd_remap2(bid, n_main);
+    gemm_tile<256, 256, NS>(a, (vid % a.n_co_tiles) * 256, (vid / a.n_co_tiles) * 256);
+    return;
+  }
+  const int t = bid - n_main;
+  const int tile = n_main + t / split, sub = t - (t / split) * split;
+  const int co_base = (tile % a.n_co_tiles) * 256, r_tile = (tile / a.n_co_tiles) * 256;
+  if (split == 4) gemm_tile<256, 64, NS>(a, co_base, r_tile + sub * 64);
+  else if (split == 2) gemm_tile<256, 128, NS>(a, co_base, r_tile + sub * 128);
+  else gemm_tile<256, 256, NS>(a, co_base, r_tile);
+}
+
 template <int TM, int TN, int NS>
 int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = NS * (TM + TN) * 128;
@@ -197,6 +224,23 @@ int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
   }
   const int grid = a.n_co_tiles * (int)ceil_div(a.R, TN);
   hipLaunchKernelGGL((gemm1x1_kernel<TM, TN, NS>), dim3(grid), dim3(512), smem, s, a);
+  SUGAR_LAUNCH_CHECK();
+  return SUGAR_OK;
+}
+
+int launch_split(const Gemm1x1Args& a, hipStream_t s) {
+  constexpr int smem = 2 * (256 + 256) * 128;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    SUGAR_HIP(hipGetDevice(&dev));
+    SUGAR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    SUGAR_HIP(hipFuncSetAttribute((const void*)gemm1x1_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  }
+  const int total = a.n_co_tiles * (int)ceil_div(a.R, 256);
+  const int n_main = total / n_cu * n_cu, tail = total - n_main;
+  const int split = tail == 0 ? 1 : tail * 4 <= n_cu ? 4 : tail * 2 <= n_cu ? 2 : 1;
+  hipLaunchKernelGGL(gemm1x1_split_kernel<2>, dim3(n_main + tail * split), dim3(512), smem, s, a, n_main, split);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
@@ -220,17 +264,11 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
   a.R = (int)R; a.cout = L.cout; a.K = L.cin_p; a.flags = L.flags;
   if (L.cout > 128) {
     a.n_co_tiles = (int)ceil_div(L.cout, 256);
-    return launch_variant<256, 256, 2>(a, s);
+    static const bool uniform = getenv("SUGAR_GEMM_UNIFORM") != nullptr;   // A/B switch: no split tail
+    return uniform ? launch_variant<256, 256, 2>(a, s) : launch_split(a, s);
   }
   a.n_co_tiles = 1;
-  static const int variant = getenv("SUGAR_POOL1_VARIANT") ? atoi(getenv("SUGAR_POOL1_VARIANT")) : 0;
-  switch (variant) {
-    case 1: return launch_variant<128, 128, 2>(a, s);
-    case 2: return launch_variant<128, 128, 4>(a, s);
-    case 3: return launch_variant<128, 256, 3>(a, s);
-    case 4: return launch_variant<128, 128, 3>(a, s);
-    default: return launch_variant<128, 64, 3>(a, s);
-  }
+  return launch_variant<128, 64, 3>(a, s);
 }
 
 }  // namespace sugar

@@ -252,8 +252,10 @@ __global__ __launch_bounds__(256) void fbank_fft_kernel(const float* __restrict_
       float s = 0.f, s2 = 0.f;                           // taps past a filter's end have zero weight
 #pragma unroll
       for (int i = 0; i < MEL_MAXW; ++i) {
-        s = fmaf(pw[min(lo0 + i, NBIN - 1)], mw0[i], s);
-        s2 = fmaf(pw[min(lo1 + i, NBIN - 1)], mw1[i], s2);
+        // lo + i may run up to 18 floats past bin 255: still inside this wave's 512-float buffer (finite leftovers of
+        // pass 3), and those taps have zero weight
+        s = fmaf(pw[lo0 + i], mw0[i], s);
+        s2 = fmaf(pw[lo1 + i], mw1[i], s2);
       }
       tile[f * SLD + mel0] = logf(s + 1e-6f);
       if (j < NMEL - 64) tile[f * SLD + mel1] = logf(s2 + 1e-6f);
