@@ -102,6 +102,22 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = a.K / TK;
+  const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
+  // folded-BN vectors of this lane's channels: with <= 4 channel tiles per wave they are fetched here, ahead of every
+  // DMA (older operations never disturb the counted vmcnt waits below), instead of stalling the epilogue
+  constexpr bool PRE = MI <= 4;
+  f32x4 scp[PRE ? MI : 1], shp[PRE ? MI : 1];
+  if (PRE) {
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+      scp[m] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      shp[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (affine) {
+        scp[m] = *(const f32x4*)(a.scale + co_base + wm * CW + m * 16 + 4 * fq);
+        shp[m] = *(const f32x4*)(a.shift + co_base + wm * CW + m * 16 + 4 * fq);
+      }
+    }
+  }
   // NS-stage ring: k-tile t+D (D = NS-1) is issued right after the barrier that opens k-tile t, into the buffer
   // k-tile t-1 was read from
   constexpr int D = NS - 1, NDMA = WI + XI;
@@ -136,7 +152,6 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
 
   // ---- epilogue --------------------------------------------------------------------------------------------
   // accumulator tile (m, n): lane (fr, fq) holds frame wn*FW + n*16 + fr, channels wm*CW + m*16 + 4 fq + {0..3}
-  const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
   unsigned char* ep = smem + wv * (16 * HN * EPI_STRIDE);     // this wave's [16 HN frames][CW channels] staging
   constexpr int CPR = CW / 8, RPP = 64 / CPR;                 // 16-byte chunks per staged row, rows per read pass
 #pragma unroll
@@ -145,7 +160,10 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
     for (int m = 0; m < MI; ++m) {
       const int col = m * 16 + 4 * fq;                        // channel within the wave's CW
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (affine) {
+      if (PRE) {
+        sc = scp[m];
+        sh = shp[m];
+      } else if (affine) {
         sc = *(const f32x4*)(a.scale + co_base + wm * CW + col);
         sh = *(const f32x4*)(a.shift + co_base + wm * CW + col);
       }
@@ -263,6 +281,14 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
   a.ldx = io.ldx; a.ldw = L.k_pad; a.ldy = io.ldy; a.ldy2 = io.ldy2; a.y2_from = io.y2_from;
   a.R = (int)R; a.cout = L.cout; a.K = L.cin_p; a.flags = L.flags;
   if (L.cout > 128) {
+    if (a.K <= 768) {
+      // short K loops (the 512-channel convs: 8 k-tiles): tile prologue and epilogue are ~1/3 of a 256 x 256 tile's
+      // time and one such workgroup fills the CU's LDS, so nothing overlaps them.  128 x 128 tiles at two
+      // workgroups per CU do (tools/gemm_variants: 0.051 vs 0.057 ms on 77056 x 512 x 512); for K = 1536 the
+      // 256 x 256 tile's lower L2 traffic and DMA issue count per MFMA win.
+      a.n_co_tiles = (int)ceil_div(L.cout, 128);
+      return launch_variant<128, 128, 2>(a, s);
+    }
     a.n_co_tiles = (int)ceil_div(L.cout, 256);
     static const bool uniform = getenv("SUGAR_GEMM_UNIFORM") != nullptr;   // A/B switch: no split tail
     return uniform ? launch_variant<256, 256, 2>(a, s) : launch_split(a, s);

@@ -114,7 +114,7 @@ __device__ __forceinline__ void fft4(float2& a, float2& b, float2& c, float2& d)
   d = make_float2(d0.x - d1.y, d0.y + d1.x);   // d0 + i d1
 }
 
-__global__ __launch_bounds__(256) void fbank_fft_kernel(const float* __restrict__ wav,
+__global__ __launch_bounds__(256, 4) void fbank_fft_kernel(const float* __restrict__ wav,
                                                         const int64_t* __restrict__ wav_off,
                                                         const int32_t* __restrict__ wav_len,
                                                         const int32_t* __restrict__ row_off, FbankTables tb,

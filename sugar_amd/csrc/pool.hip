@@ -42,7 +42,7 @@ constexpr int PC = 256;    // channels per workgroup
 constexpr int BOTT = 128;
 
 template <typename T>
-__global__ __launch_bounds__(512) void pool_stats_kernel(const T* __restrict__ a, int lda, const T* __restrict__ h,
+__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel(const T* __restrict__ a, int lda, const T* __restrict__ h,
                                                          int ldh, const T* __restrict__ w2, int ccat_p,
                                                          const int32_t* __restrict__ row_off,
                                                          float* __restrict__ pooled) {
@@ -74,37 +74,37 @@ __global__ __launch_bounds__(512) void pool_stats_kernel(const T* __restrict__ a
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
-      // unconditional load from a clamped row, then select (no branch around the load: keeps the loads pipelined)
-      const u32x4 v = *(const u32x4*)(a + (size_t)(s + min(t0 + row, n - 1)) * lda + ch * E);
-      areg[i] = t0 + row < n ? v : (u32x4){0u, 0u, 0u, 0u};
+      // unconditional load from a clamped row; the zero-select happens in store_tile, one tile later, so nothing
+      // waits on the load here and it stays in flight under this tile's MFMAs and exps
+      areg[i] = *(const u32x4*)(a + (size_t)(s + min(t0 + row, n - 1)) * lda + ch * E);
     }
 #pragma unroll
     for (int i = 0; i < H_PER; ++i) {
       const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
       const int cc = min(c_base + ch * E, ccat_p - E);
-      const u32x4 v = *(const u32x4*)(h + (size_t)(s + min(t0 + row, n - 1)) * ldh + cc);
-      hreg[i] = (t0 + row < n && c_base + ch * E < ccat_p) ? v : (u32x4){0u, 0u, 0u, 0u};
+      hreg[i] = *(const u32x4*)(h + (size_t)(s + min(t0 + row, n - 1)) * ldh + cc);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int t0) {
     unsigned char* ab = smem + buf * (A_BYTES + H_BYTES);
     unsigned char* hb = ab + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
-      *(u32x4*)(ab + row * (A_CH * 16) + ((ch ^ (row & 15)) << 4)) = areg[i];
+      *(u32x4*)(ab + row * (A_CH * 16) + ((ch ^ (row & 15)) << 4)) = t0 + row < n ? areg[i] : (u32x4){0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int i = 0; i < H_PER; ++i) {
-      const int idx = tid + i * 512;
-      *(u32x4*)(hb + idx * 16) = hreg[i];          // plain [row][channel] image
+      const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
+      const bool ok = t0 + row < n && c_base + ch * E < ccat_p;
+      *(u32x4*)(hb + idx * 16) = ok ? hreg[i] : (u32x4){0u, 0u, 0u, 0u};          // plain [row][channel] image
     }
   };
 
   float m = -1e30f, l = 0.f, s1 = 0.f, s2 = 0.f;
   const int ntiles = (n + PT - 1) / PT;
   load_tile(0);
-  store_tile(0);
+  store_tile(0, 0);
   __syncthreads();
   for (int it = 0; it < ntiles; ++it) {
     const int t0 = it * PT;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512) void pool_stats_kernel(const T* __restrict__ a
       s1 += ph;
       s2 = fmaf(ph, hv[e], s2);
     }
-    if (more) store_tile((it + 1) & 1);
+    if (more) store_tile((it + 1) & 1, t0 + PT);
     __syncthreads();
   }
   // merge the two half-waves (same channel, disjoint frames)

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ y, 
 
 // ------------------------------------------------------------------------------------------ tail
 constexpr int TAIL_U = 16;    // utterances per workgroup
-constexpr int TAIL_K = 512;   // pooled features per k-split
+constexpr int TAIL_K = 128;   // pooled features per k-split (24 splits at 3072 features: 1152 workgroups, short dependent-load chains)
 
 // partial[ks][b][o] = sum_{i in k-split ks} wt[i][o] * pooled[b][i]
 __global__ __launch_bounds__(256) void tail_partial_kernel(const float* __restrict__ wt, int in_p, int embed,
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(const float* __restri
 #pragma unroll
   for (int u = 0; u < TAIL_U; ++u) acc[u] = 0.f;
   const bool o_ok = o < embed;
-#pragma unroll 4
+#pragma unroll 8
   for (int i = kl; i < kn; i += 4) {
     const float w = o_ok ? wt[(size_t)(k0 + i) * embed + o] : 0.f;
 #pragma unroll
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void tail_finalize_kernel(const float* __restr
   float ss = 0.f;
   for (int o = tid; o < embed; o += 256) {
     float t = bias[o];
-    for (int k = 0; k < ks; ++k) t += partial[((size_t)k * B + b) * embed + o];
+#pragma unroll 8
+    for (int k = 0; k < ks; ++k) t += partial[((size_t)k * B + b) * embed + o];   // fixed order: deterministic
     emb[(size_t)b * embed + o] = t;
     ss = fmaf(t, t, ss);
   }
