@@ -154,10 +154,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(Args a) {
     };
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (!(V & 1) && kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      if (!(V & 1) && !((V & 128) && wm == 1) && kt + 1 < nk) stage(cur ^ 1, kt + 1);
       const unsigned char* wb = smem + ((V & 1) ? 0 : cur) * STAGE_BYTES;
       const unsigned char* xb = wb + TM * 128;
-      if constexpr (V & 32) {
+      if constexpr (V & 128) {
+        // staggered DMA issue: waves 0-3 issue before their MFMAs, waves 4-7 between their two MFMA halves
+        {
+          bf16x8 af[8], bf[4];
+          load_frags(wb, xb, 0, af, bf);
+          mma(af, bf);
+        }
+        if (wm == 1 && kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        {
+          bf16x8 af[8], bf[4];
+          load_frags(wb, xb, 1, af, bf);
+          mma(af, bf);
+        }
+      } else if constexpr (V & 32) {
         bf16x8 af0[8], bf0[4], af1[8], bf1[4];
         load_frags(wb, xb, 0, af0, bf0);
         load_frags(wb, xb, 1, af1, bf1);
@@ -392,6 +405,9 @@ int main(int argc, char** argv) {
     printf("gemm5 vs base: %zu mismatches of %zu\n", bad, y0.size());
   }
   for (int round = 0; round < 3; ++round) {
+    printf("  stagger      %.4f ms\n", run<128>(a, grid, 10));
+    printf("  stagger+raw  %.4f ms\n", run<144>(a, grid, 10));
+    printf("  base         %.4f ms\n", run<0>(a, grid, 10));
     printf("  gemm5        %.4f ms\n", run5<0>(a, grid, 10));
     printf("  gemm5+prio   %.4f ms\n", run5<8>(a, grid, 10));
     printf("  gemm5 noSt   %.4f ms\n", run5<4>(a, grid, 10));
