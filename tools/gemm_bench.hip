@@ -152,6 +152,57 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(Args a) {
         if constexpr (V & 8) __builtin_amdgcn_s_setprio(0);
       }
     };
+    if constexpr (V & 768) {
+      // 256: X operand through registers (global_load_dwordx4 -> ds_write_b128), W by LDS-DMA; 512: both through registers
+      const bf16* xlin[4];
+      const bf16* wlin[4];
+      int dst[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wv * 32 + i * 8 + srow, c = lane & 7;
+        xlin[i] = a.x + (size_t)min(r_base + row, a.R - 1) * a.ldx + c * 8;
+        wlin[i] = a.w + (size_t)(co_base + row) * a.ldw + c * 8;
+        dst[i] = swz(row, c);
+      }
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        u32x4 xr[4], wr[4];
+        if (more) {
+          if (!(V & 512)) {
+            unsigned char* base = smem + (cur ^ 1) * STAGE_BYTES + wv * 32 * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (kt + 1) * TK),
+                                               (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xr[i] = *(const u32x4*)(xlin[i] + (kt + 1) * TK);
+          if (V & 512) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wr[i] = *(const u32x4*)(wlin[i] + (kt + 1) * TK);
+          }
+        }
+        const unsigned char* wb = smem + cur * STAGE_BYTES;
+        const unsigned char* xb = wb + TM * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 af[8], bf[4];
+          load_frags(wb, xb, s, af, bf);
+          mma(af, bf);
+        }
+        if (more) {
+          unsigned char* nb = smem + (cur ^ 1) * STAGE_BYTES;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *(u32x4*)(nb + TM * 128 + dst[i]) = xr[i];
+          if (V & 512) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(nb + dst[i]) = wr[i];
+          }
+        }
+        barrier();
+      }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       if (!(V & 1) && !((V & 128) && wm == 1) && kt + 1 < nk) stage(cur ^ 1, kt + 1);
@@ -403,8 +454,22 @@ int main(int argc, char** argv) {
     size_t bad = 0;
     for (size_t i = 0; i < y0.size(); ++i) bad += y0[i] != y1[i];
     printf("gemm5 vs base: %zu mismatches of %zu\n", bad, y0.size());
+    CK(hipMemset(y, 0, y0.size() * 2));
+    run<256>(a, grid, 1);
+    CK(hipMemcpy(y1.data(), y, y1.size() * 2, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < y0.size(); ++i) bad += y0[i] != y1[i];
+    printf("Xreg vs base: %zu mismatches\n", bad);
+    CK(hipMemset(y, 0, y0.size() * 2));
+    run<512>(a, grid, 1);
+    CK(hipMemcpy(y1.data(), y, y1.size() * 2, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < y0.size(); ++i) bad += y0[i] != y1[i];
+    printf("XWreg vs base: %zu mismatches\n", bad);
   }
   for (int round = 0; round < 3; ++round) {
+    printf("  Xreg+Wdma    %.4f ms\n", run<256>(a, grid, 10));
+    printf("  XWreg        %.4f ms\n", run<512>(a, grid, 10));
     printf("  stagger      %.4f ms\n", run<128>(a, grid, 10));
     printf("  stagger+raw  %.4f ms\n", run<144>(a, grid, 10));
     printf("  base         %.4f ms\n", run<0>(a, grid, 10));
