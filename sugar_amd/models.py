@@ -160,3 +160,39 @@ def bn_state_dict(model, removed_prefix=""):
         if leaf in keys and (prefix.endswith(".bn") or prefix.endswith("bnpool") or prefix.endswith("bnembed")):
             out[k.replace(removed_prefix, "")] = v
     return out
+
+
+def veri_validate(loader, model, args=None, tboard=None, norm=True, p_target=0.05, device="cuda:0", mode="cosine",
+                  ret_info=False, vectors=None):
+    """
+    Speaker-verification evaluation (sugar/models/__init__.py:535-595): extract the vectors of
+    `loader.dataset.utterances` (skipped when `vectors` is given), score `loader.dataset`'s trials, return
+    ((eer, thresh), (mindcf, thresh)) -- plus (vectors, scores) with ret_info=True.  `loader` is anything with the
+    reference DataLoader's attributes (`dataset` iterable of {"label", "enroll", "test"} with `.utterances`,
+    `batch_size`, `num_workers`); `args.gpu` selects the device as in the reference; `tboard` receives the same
+    two scalars when given.
+    """
+    from .metrics import calculate_eer, calculate_mindcf
+    from .scores import score_trials
+    from .vectors import extract_vectors
+
+    val_task = "evaluate"
+    if args is not None:
+        val_task = "test" if getattr(args, "evaluate", False) is True else "validate"
+        if getattr(args, "gpu", None) is None:
+            raise _lib.SugarError("sugar_amd runs on an MI355X only: args.gpu must name a device (no CPU fallback)")
+        device = "cuda:{}".format(args.gpu)
+    name = "Cuda:{}".format(device.split(":")[1]) if ":" in device else "Cuda:0"
+    if vectors is None:
+        with torch.no_grad():
+            vectors = extract_vectors(model, loader.dataset.utterances, norm=norm, device=device,
+                                      n_jobs=getattr(loader, "num_workers", 0), batch_size=loader.batch_size)
+    scs, labs, _ = score_trials(loader.dataset, vectors, mode=mode, n_jobs=1)
+    eer = calculate_eer(labs, scs)
+    dcf = calculate_mindcf(labs, scs, p_target=p_target)
+    if tboard is not None:
+        tboard.add_scalars("Metric/%s/EER" % val_task, {name: eer[0]}, args.epoch)
+        tboard.add_scalars("Metric/%s/DCF" % val_task, {name: dcf[0]}, args.epoch)
+    if not ret_info:
+        return eer, dcf
+    return eer, dcf, vectors, scs

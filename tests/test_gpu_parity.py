@@ -159,6 +159,41 @@ def test_extract_vectors_and_score_trials_ordering(supernet):
     assert np.array_equal(np.argsort(scores, kind="stable"), np.argsort(want[keep], kind="stable"))
 
 
+class _Trials(list):
+    """Stands in for sugar.database.VerificationTrials: iterable of trials + `.utterances`."""
+    utterances = None
+
+
+class _Loader:
+    def __init__(self, dataset, batch_size):
+        self.dataset, self.batch_size, self.num_workers = dataset, batch_size, 0
+
+
+def test_veri_validate_matches_oracle_pipeline(supernet):
+    """veri_validate (models/__init__.py:535-595): extraction + scoring on the GPU, EER / minDCF on the host; the same
+    numbers as oracle embeddings + oracle scoring + the metrics module (itself pinned to the reference's metrics)."""
+    from sugar_amd import metrics
+    model = _model(supernet, layout.SMALLEST, "fp32")
+    n_utts = 16
+    lens = synth.ragged_lengths(n_utts, lo=24000, hi=48000, seed=9).tolist()
+    wavs = synth.ragged_waveforms(lens, seed=9)
+    lab, a, b = synth.trial_pairs(n_utts, 200, seed=9)
+    trials = _Trials({"label": int(lab[i]), "enroll": "utt%04d.wav" % a[i], "test": "utt%04d.wav" % b[i]}
+                     for i in range(len(lab)))
+    trials.utterances = _Utts(wavs, [1] * n_utts)
+    eer, dcf, vectors, scs = sugar_amd.veri_validate(_Loader(trials, 4), model, device=DEV, p_target=0.05,
+                                                     ret_info=True)
+    osd = ref_cpu.clone_state(synth.fill_state_dict(layout.supernet_shapes(), seed=0), layout.SMALLEST)
+    want_vecs = [ref_cpu.embed(osd, layout.SMALLEST[0], w.unsqueeze(0), norm=True) for w in wavs]
+    want_scs = ref_cpu.score_trials(a, b, want_vecs)
+    assert np.abs(scs - want_scs).max() < 1e-4
+    assert abs(eer[0] - metrics.calculate_eer(lab, want_scs)[0]) < 0.02        # 200 trials: one swap = 1 %
+    assert abs(dcf[0] - metrics.calculate_mindcf(lab, want_scs, p_target=0.05)[0]) < 0.05
+    # vectors= short-circuits extraction and reproduces the same numbers exactly
+    eer2, dcf2 = sugar_amd.veri_validate(_Loader(trials, 4), model, device=DEV, vectors=vectors)
+    assert eer2 == eer and dcf2 == dcf
+
+
 def test_full_size_batch256_properties(supernet):
     """BASELINE config 2 size (256 x 3 s, Base, bf16): size-independent properties instead of a CPU oracle run."""
     model = _model(supernet, layout.BASE, "bf16")
