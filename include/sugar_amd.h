@@ -133,6 +133,34 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
                     const int32_t* d_wav_len, const int32_t* d_row_off, int B, int64_t R, int t_max,
                     void* d_workspace, int64_t workspace_bytes, float* d_emb, int normalize, void* stream);
 
+/* ---- BN recalibration ---------------------------------------------------------------
+ * Replaces: one iteration of batch_forward (sugar/models/__init__.py:201-242): `model.train(); model.forward(x, None)`
+ * -- every BatchNorm normalises with the statistics of THIS batch (biased variance over all frames / utterances of
+ * the batch, DynamicBatchNorm1d.forward, sugar/modules/dynamicarch.py:254-291) and moves its running statistics by
+ * `momentum` (nn.BatchNorm1d default 0.1; unbiased variance in the running update).  The running statistics live in
+ * the handle; the eval-mode entry points keep using the statistics of the last sugar_subnet_bn_commit.
+ * d_emb (may be NULL) receives the train-mode embeddings [B][embed].  B must be > 1 (as torch requires). */
+int sugar_tdnn_recalibrate(SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R,
+                           int t_max, void* d_workspace, int64_t workspace_bytes, float momentum, float* d_emb,
+                           void* stream);
+/* = sugar_fbank_fwd + sugar_tdnn_recalibrate (SpeakerModel.forward in train(), models/__init__.py:96-105). */
+int sugar_embed_recalibrate(SugarSubnet* net, const float* d_wav, const int64_t* d_wav_off,
+                            const int32_t* d_wav_len, const int32_t* d_row_off, int B, int64_t R, int t_max,
+                            void* d_workspace, int64_t workspace_bytes, float momentum, float* d_emb, void* stream);
+/* BatchNorm layers of a packed subnet, in state-dict order: 0 layer1.bn; 1 + 9*i + {0 first_conv.bn,
+ * 1..7 resconv.convs.(k-1).bn, 8 last_conv.bn} for block i; 1 + 9*depth bnpool; 2 + 9*depth bnembed. */
+int sugar_subnet_bn_count(const SugarSubnet* net);
+/* Replaces: reading bn.running_mean / bn.running_var after batch_forward (bn_state_dict, sugar/utils/utility.py:9-24):
+ * copies the current running statistics of BatchNorm `bn_index` to host arrays of n = its channel count, in the
+ * reference's channel order.  Synchronises the device. */
+int sugar_subnet_bn_read(SugarSubnet* net, int bn_index, float* h_mean, float* h_var, int n);
+/* Replaces: nn.BatchNorm1d.reset_running_stats on every BN of the subnet (mean 0, var 1). */
+int sugar_subnet_bn_reset(SugarSubnet* net);
+/* Re-derives the folded (scale, shift) vectors and the folded tail from the current running statistics, so that
+ * the eval-mode entry points use them (the reference needs no such step: `model.eval()` reads the buffers).
+ * Synchronises the device. */
+int sugar_subnet_bn_commit(SugarSubnet* net);
+
 /* Debug / parity tap: runs sugar_tdnn_fwd (un-normalised embeddings to d_emb) and additionally copies one
  * intermediate activation, converted to float32, to d_out as [R][C] in the library's INTERNAL channel layout
  * (channels padded to multiples of 8; Res2 groups padded per group -- see DESIGN.md "data layout").

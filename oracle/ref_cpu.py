@@ -195,9 +195,15 @@ def clone_state(sup: dict, config, num_blocks: int = 4, channels: int = 512, cat
 
 
 # --------------------------------------------------------------------------- backbone forward
+_TRAIN_MOMENTUM = None      # set by subnet_forward(train_momentum=...): train-mode BN, running stats updated in place
+
+
 def _bn(x, sd, prefix):
+    """Eval-mode BN, or -- inside subnet_forward(train_momentum=m) -- nn.BatchNorm1d in train(): batch statistics,
+    running_mean / running_var of `sd` updated in place (DynamicBatchNorm1d.forward, dynamicarch.py:254-263)."""
+    train = _TRAIN_MOMENTUM is not None
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
-                        sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.0, BN_EPS)
+                        sd[prefix + ".weight"], sd[prefix + ".bias"], train, _TRAIN_MOMENTUM if train else 0.0, BN_EPS)
 
 
 def _conv(x, w, dilation=1):
@@ -210,11 +216,23 @@ def _conv_relu_bn(x, sd, prefix, dilation=1):
     return _bn(F.relu(_conv(x, sd[prefix + ".conv.weight"], dilation)), sd, prefix + ".bn")
 
 
-def subnet_forward(sd: dict, depth: int, feats: torch.Tensor, stages: dict = None) -> torch.Tensor:
+def subnet_forward(sd: dict, depth: int, feats: torch.Tensor, stages: dict = None,
+                   train_momentum: float = None) -> torch.Tensor:
     """
     Cloned-subnet forward (DynamicTDNN.forward, dynamictdnn.py:645-666) on a cloned state dict.
     feats [B, 80, T] -> [B, 192].  If ``stages`` is a dict, per-stage activations are stored in it.
+    ``train_momentum``: run as one batch_forward step (sugar/models/__init__.py:230-238: model.train(); forward) --
+    every BN uses this batch's statistics and updates the running statistics held in ``sd`` IN PLACE.
     """
+    global _TRAIN_MOMENTUM
+    _TRAIN_MOMENTUM = train_momentum
+    try:
+        return _subnet_forward(sd, depth, feats, stages)
+    finally:
+        _TRAIN_MOMENTUM = None
+
+
+def _subnet_forward(sd, depth, feats, stages):
     def keep(name, t):
         if stages is not None:
             stages[name] = t.clone()

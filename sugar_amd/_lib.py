@@ -56,6 +56,12 @@ SYMBOLS = {
     "sugar_profile_read": (_i, [_i, C.POINTER(_i), C.POINTER(C.c_double)]),
     "sugar_profile_stage_name": (C.c_char_p, [_i]),
     "sugar_cosine_trials": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
+    "sugar_tdnn_recalibrate": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _i64, C.c_float, _vp, _vp]),
+    "sugar_embed_recalibrate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _i64, C.c_float, _vp, _vp]),
+    "sugar_subnet_bn_count": (_i, [_vp]),
+    "sugar_subnet_bn_read": (_i, [_vp, _i, _fp, _fp, _i]),
+    "sugar_subnet_bn_reset": (_i, [_vp]),
+    "sugar_subnet_bn_commit": (_i, [_vp]),
 }
 
 _lib = None

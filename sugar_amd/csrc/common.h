@@ -162,6 +162,28 @@ int launch_tail(const TailLayer& t, const float* d_pooled, int B, float* d_parti
                 hipStream_t s);
 int launch_l2norm(float* d_x, int64_t n, int dim, hipStream_t s);
 
+// ---- train-mode BatchNorm for BN recalibration (bn_recal.hip) ------------------------------------
+struct BNState {            // device f32 [4][n]: gamma | beta | running_mean | running_var, packed channel order
+  float* p = nullptr;
+  int n = 0;                // packed channels (padded ones: gamma 0, beta 0, mean 0, var 1)
+  int c = 0;                // reference channels
+  int* h_map = nullptr;     // host: reference channel -> packed index
+  float* gamma() const { return p; }
+  float* beta() const { return p + n; }
+  float* mean() const { return p + 2 * (size_t)n; }
+  float* var() const { return p + 3 * (size_t)n; }
+};
+int bn_state_create(BNState* st, const SugarBN* bn, int c, int n_packed, const int* map);
+void bn_state_free(BNState* st);
+int bn_workspace_doubles(int c_max);
+// z [R][C] (row stride ld, compute dtype) <- train-mode BN of z, in place; running statistics of st updated
+int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, float momentum, double* d_part,
+                    float* d_scale, float* d_shift, int dtype, hipStream_t s);
+// x [B][ld] f32 <- train-mode BN over the B rows, in place (st.n channels)
+int launch_bn_rows(float* d_x, int ld, int B, const BNState& st, float momentum, hipStream_t s);
+// (scale, shift) of eval-mode BN from the running statistics
+int launch_bn_fold(const BNState& st, float* d_scale, float* d_shift, hipStream_t s);
+
 // dtype -> f32 copy of a strided [R][C] activation (debug taps)
 int launch_to_f32(const void* d_x, int ldx, int64_t R, int C, float* d_out, int dtype, hipStream_t s);
 

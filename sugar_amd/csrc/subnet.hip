@@ -64,6 +64,7 @@ struct Prof {
 struct Block {
   ConvLayer first, res[SUGAR_RES2_SCALE - 1], last;
   SELayer se;
+  BNState bn_first, bn_res[SUGAR_RES2_SCALE - 1], bn_last;   // raw BN parameters + running statistics (recalibration)
   int w = 0, wp = 0, midp = 0, kernel = 1;
 };
 
@@ -76,6 +77,10 @@ struct SugarSubnet {
   sugar::Block blocks[SUGAR_MAX_DEPTH];
   sugar::PoolLayer pool;
   sugar::TailLayer tail;
+  // BN recalibration: raw BN state of every BatchNorm, the unfolded linear layer, host copies for the tail refold
+  sugar::BNState bn_layer1, bn_pool, bn_embed;
+  sugar::TailLayer tail_raw;
+  std::vector<float> h_linear_w, h_linear_b;
 };
 
 namespace sugar {
@@ -101,11 +106,53 @@ static void destroy(SugarSubnet* n) {
     if (b.se.b1) (void)hipFree(b.se.b1);
     if (b.se.w2t) (void)hipFree(b.se.w2t);
     if (b.se.b2) (void)hipFree(b.se.b2);
+    bn_state_free(&b.bn_first);
+    bn_state_free(&b.bn_last);
+    for (auto& r : b.bn_res) bn_state_free(&r);
   }
   if (n->pool.w2) (void)hipFree(n->pool.w2);
   if (n->tail.wt) (void)hipFree(n->tail.wt);
   if (n->tail.bias) (void)hipFree(n->tail.bias);
+  if (n->tail_raw.wt) (void)hipFree(n->tail_raw.wt);
+  if (n->tail_raw.bias) (void)hipFree(n->tail_raw.bias);
+  bn_state_free(&n->bn_layer1);
+  bn_state_free(&n->bn_pool);
+  bn_state_free(&n->bn_embed);
   delete n;
+}
+
+// tail: bnembed(linear(bnpool(p))) = W' p + b'  folded in double               dynamictdnn.py:664-665
+// BN arrays in reference channel order (gamma, beta, running_mean, running_var); the first call allocates.
+static int fold_tail(SugarSubnet* n, const float* const pool_bn[4], const float* const embed_bn[4]) {
+  const int in = 2 * n->ccat, inp = 2 * n->ccatp, E_ = n->embed;
+  std::vector<float> wt((size_t)inp * E_, 0.f), bias(E_);
+  std::vector<double> sp(in), tp(in);
+  for (int i = 0; i < in; ++i) {
+    sp[i] = (double)pool_bn[0][i] / sqrt((double)pool_bn[3][i] + 1e-5);
+    tp[i] = (double)pool_bn[1][i] - (double)pool_bn[2][i] * sp[i];
+  }
+  for (int o = 0; o < E_; ++o) {
+    const double se = (double)embed_bn[0][o] / sqrt((double)embed_bn[3][o] + 1e-5);
+    const double te = (double)embed_bn[1][o] - (double)embed_bn[2][o] * se;
+    double acc = n->h_linear_b[o];
+    for (int i = 0; i < in; ++i) {
+      const double wv = n->h_linear_w[(size_t)o * in + i];
+      acc += wv * tp[i];
+      const int pi = i < n->ccat ? i : n->ccatp + (i - n->ccat);
+      wt[(size_t)pi * E_ + o] = (float)(se * wv * sp[i]);
+    }
+    bias[o] = (float)(se * acc + te);
+  }
+  if (!n->tail.wt) {
+    int rc;
+    if ((rc = upload(&n->tail.wt, wt)) || (rc = upload(&n->tail.bias, bias))) return rc;
+  } else {
+    SUGAR_HIP(hipMemcpy(n->tail.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+    SUGAR_HIP(hipMemcpy(n->tail.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  n->tail.in_p = inp;
+  n->tail.embed = E_;
+  return SUGAR_OK;
 }
 
 static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
@@ -123,7 +170,8 @@ static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
 
   // layer1: (in_feats, C0, K0), dilation 1                                         dynamictdnn.py:628
   if ((rc = pack_conv(&n->layer1, d->layer1_w, &d->layer1_bn, d->c0, d->in_feats, d->k0, 1, EPI_RELU, n->c0p, nullptr,
-                      d->in_feats, nullptr, dtype)))
+                      d->in_feats, nullptr, dtype)) ||
+      (rc = bn_state_create(&n->bn_layer1, &d->layer1_bn, d->c0, n->c0p, nullptr)))
     return rc;
 
   for (int i = 0; i < d->depth; ++i) {
@@ -144,16 +192,19 @@ static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
     for (int g = 0; g < SUGAR_RES2_SCALE; ++g)
       for (int j = 0; j < b.w; ++j) midmap[g * b.w + j] = g * b.wp + j;
     if ((rc = pack_conv(&b.first, sb.first_w, &sb.first_bn, sb.mid_channels, d->c0, 1, 1, EPI_RELU, b.midp,
-                        midmap.data(), n->c0p, nullptr, dtype)))
+                        midmap.data(), n->c0p, nullptr, dtype)) ||
+        (rc = bn_state_create(&b.bn_first, &sb.first_bn, sb.mid_channels, b.midp, midmap.data())))
       return rc;
     for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {
       SUGAR_CHECK_ARG(sb.res_w[j] && bn_ok(sb.res_bn[j]), "block %d res2 conv %d: null tensor", i, j);
       if ((rc = pack_conv(&b.res[j], sb.res_w[j], &sb.res_bn[j], b.w, b.w, sb.kernel, dil, EPI_RELU, b.wp, nullptr,
-                          b.wp, nullptr, dtype)))
+                          b.wp, nullptr, dtype)) ||
+          (rc = bn_state_create(&b.bn_res[j], &sb.res_bn[j], b.w, b.wp, nullptr)))
         return rc;
     }
     if ((rc = pack_conv(&b.last, sb.last_w, &sb.last_bn, d->c0, sb.mid_channels, 1, 1, EPI_RELU, n->c0p, nullptr,
-                        b.midp, midmap.data(), dtype)))
+                        b.midp, midmap.data(), dtype)) ||
+        (rc = bn_state_create(&b.bn_last, &sb.last_bn, d->c0, n->c0p, nullptr)))
       return rc;
     // SE: reduce [hid][c0], expand [c0][hid]  -> transposed, channel-padded             dynamictdnn.py:88-89
     const int hid = d->c0 / 4;
@@ -205,30 +256,25 @@ static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
     n->pool.ccat_p = n->ccatp;
     n->pool.bott = d->bottleneck;
   }
-  // tail: bnembed(linear(bnpool(p))) = W' p + b'                                      dynamictdnn.py:664-665
+  // tail: folded affine for eval, raw linear + BN states for recalibration
   {
     const int in = 2 * d->ccat, inp = 2 * n->ccatp, E_ = d->embed_dim;
-    std::vector<float> wt((size_t)inp * E_, 0.f), bias(E_);
-    std::vector<double> sp(in), tp(in);
-    for (int i = 0; i < in; ++i) {
-      sp[i] = (double)d->bnpool.weight[i] / sqrt((double)d->bnpool.running_var[i] + 1e-5);
-      tp[i] = (double)d->bnpool.bias[i] - (double)d->bnpool.running_mean[i] * sp[i];
-    }
-    for (int o = 0; o < E_; ++o) {
-      const double se = (double)d->bnembed.weight[o] / sqrt((double)d->bnembed.running_var[o] + 1e-5);
-      const double te = (double)d->bnembed.bias[o] - (double)d->bnembed.running_mean[o] * se;
-      double acc = d->linear_b[o];
-      for (int i = 0; i < in; ++i) {
-        const double wv = d->linear_w[(size_t)o * in + i];
-        acc += wv * tp[i];
-        const int pi = i < d->ccat ? i : n->ccatp + (i - d->ccat);
-        wt[(size_t)pi * E_ + o] = (float)(se * wv * sp[i]);
-      }
-      bias[o] = (float)(se * acc + te);
-    }
-    if ((rc = upload(&n->tail.wt, wt)) || (rc = upload(&n->tail.bias, bias))) return rc;
-    n->tail.in_p = inp;
-    n->tail.embed = E_;
+    n->h_linear_w.assign(d->linear_w, d->linear_w + (size_t)E_ * in);
+    n->h_linear_b.assign(d->linear_b, d->linear_b + E_);
+    const float* const pool_bn[4] = {d->bnpool.weight, d->bnpool.bias, d->bnpool.running_mean, d->bnpool.running_var};
+    const float* const embed_bn[4] = {d->bnembed.weight, d->bnembed.bias, d->bnembed.running_mean, d->bnembed.running_var};
+    if ((rc = fold_tail(n, pool_bn, embed_bn))) return rc;
+    std::vector<int> poolmap(in);
+    for (int i = 0; i < in; ++i) poolmap[i] = i < d->ccat ? i : n->ccatp + (i - d->ccat);
+    if ((rc = bn_state_create(&n->bn_pool, &d->bnpool, in, inp, poolmap.data())) ||
+        (rc = bn_state_create(&n->bn_embed, &d->bnembed, E_, E_, nullptr)))
+      return rc;
+    std::vector<float> wraw((size_t)inp * E_, 0.f);
+    for (int o = 0; o < E_; ++o)
+      for (int i = 0; i < in; ++i) wraw[(size_t)poolmap[i] * E_ + o] = d->linear_w[(size_t)o * in + i];
+    if ((rc = upload(&n->tail_raw.wt, wraw)) || (rc = upload(&n->tail_raw.bias, n->h_linear_b))) return rc;
+    n->tail_raw.in_p = inp;
+    n->tail_raw.embed = E_;
   }
   (void)E;
   return fbank_init();
@@ -240,6 +286,8 @@ struct Workspace {
   float* logmel;
   void *feats, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
   float *semean, *sescale, *pooled, *tailpart;
+  double* bnpart;    // recalibration: partial sums, batch (scale, shift), pre-BN embeddings
+  float *bnscale, *bnshift, *embpre;
   int64_t bytes;
 };
 
@@ -266,6 +314,11 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   w.sescale = (float*)take((int64_t)B * n->c0p * 4);
   w.pooled = (float*)take((int64_t)B * 2 * n->ccatp * 4);
   w.tailpart = (float*)take((int64_t)tail_splits(n->tail) * B * n->embed * 4);
+  const int cbn = n->c0p > n->midp_max ? n->c0p : n->midp_max;
+  w.bnpart = (double*)take((int64_t)bn_workspace_doubles(cbn) * 8);
+  w.bnscale = (float*)take((int64_t)cbn * 4);
+  w.bnshift = (float*)take((int64_t)cbn * 4);
+  w.embpre = (float*)take((int64_t)B * n->embed * 4);
   w.bytes = off;
   return w;
 }
@@ -340,6 +393,109 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     SUGAR_HIP(hipMemcpyAsync(tap_out, w.pooled, (size_t)B * 2 * n->ccatp * 4, hipMemcpyDeviceToDevice, s));
   Prof p(SUGAR_STAGE_TAIL, s);
   if ((rc = launch_tail(n->tail, w.pooled, B, w.tailpart, d_emb, normalize, s))) return rc;
+  return SUGAR_OK;
+}
+
+// ---------------------------------------------------------------------------------- BN recalibration
+// One train-mode forward (batch_forward, sugar/models/__init__.py:201-242): same schedule as tdnn_forward, but every
+// conv -> ReLU -> BN runs as conv+ReLU (affine off), then BatchNorm with the statistics of THIS batch, in place, and
+// the BN's running statistics move by `momentum`.  The Res2 chain runs step by step (each step's BN needs a
+// reduction over all utterances), the tail unfolded (bnpool -> linear -> bnembed).  d_emb receives the train-mode
+// embeddings (what the reference's forward returns in train()).
+static ConvLayer raw_conv(const ConvLayer& L) {
+  ConvLayer r = L;
+  r.flags = L.flags & ~EPI_AFFINE;
+  r.scale = r.shift = nullptr;
+  return r;
+}
+
+static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* row_off, int B, int64_t R, int t_max,
+                            const Workspace& w, float momentum, float* d_emb, hipStream_t s) {
+  const int dt = n->dtype;
+  const int64_t esz = dt == SUGAR_F32 ? 4 : 2;
+  int rc;
+  auto col = [&](void* p, int64_t c) { return (void*)((char*)p + c * esz); };
+  auto bn = [&](void* z, int ld, int C, const BNState& st) {
+    return launch_bn_batch(z, ld, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s);
+  };
+  if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc;
+
+  ConvIO io;
+  io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
+  if ((rc = launch_conv(raw_conv(n->layer1), io, w.rowseg, R, dt, s)) || (rc = bn(w.S, n->c0p, n->c0p, n->bn_layer1)))
+    return rc;
+
+  const int ldcat = n->depth * n->c0p;
+  for (int i = 0; i < n->depth; ++i) {
+    const Block& b = n->blocks[i];
+    const void* xin = i == 0 ? w.S : col(w.cat, (int64_t)(i - 1) * n->c0p);
+    const int ldin = i == 0 ? n->c0p : ldcat;
+    ConvIO f;
+    f.x = xin; f.ldx = ldin; f.y = w.mid1; f.ldy = b.midp;
+    if ((rc = launch_conv(raw_conv(b.first), f, w.rowseg, R, dt, s)) || (rc = bn(w.mid1, b.midp, b.midp, b.bn_first)))
+      return rc;
+    for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {                              // dynamictdnn.py:294-299
+      ConvIO r;
+      r.x = col(w.mid1, (int64_t)j * b.wp); r.ldx = b.midp;
+      if (j > 0) { r.x2 = col(w.mid2, (int64_t)(j - 1) * b.wp); r.ldx2 = b.midp; }
+      r.y = col(w.mid2, (int64_t)j * b.wp); r.ldy = b.midp;
+      if ((rc = launch_conv(raw_conv(b.res[j]), r, w.rowseg, R, dt, s)) ||
+          (rc = bn(r.y, b.midp, b.wp, b.bn_res[j])))
+        return rc;
+    }
+    // the 8th split passes through (:300-301): the normalised first_conv columns
+    const int64_t c7 = (int64_t)(SUGAR_RES2_SCALE - 1) * b.wp;
+    SUGAR_HIP(hipMemcpy2DAsync(col(w.mid2, c7), (size_t)b.midp * esz, col(w.mid1, c7), (size_t)b.midp * esz,
+                               (size_t)b.wp * esz, (size_t)R, hipMemcpyDeviceToDevice, s));
+    ConvIO l;
+    l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
+    if ((rc = launch_conv(raw_conv(b.last), l, w.rowseg, R, dt, s)) || (rc = bn(w.ybuf, n->c0p, n->c0p, b.bn_last)))
+      return rc;
+    if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, w.semean, w.sescale, dt, s))) return rc;
+    void* out = col(w.cat, (int64_t)i * n->c0p);
+    if ((rc = launch_se_apply(w.ybuf, n->c0p, w.sescale, n->c0p, w.S, n->c0p, out, ldcat, i + 1 < n->depth, row_off, B,
+                              t_max, dt, s)))
+      return rc;
+  }
+  ConvIO c;
+  c.x = w.cat; c.ldx = ldcat; c.y = w.hbuf; c.ldy = n->ccatp;
+  if ((rc = launch_conv(n->catconv, c, w.rowseg, R, dt, s))) return rc;
+  ConvIO p1;
+  p1.x = w.hbuf; p1.ldx = n->ccatp; p1.y = w.abuf; p1.ldy = n->bott;
+  if ((rc = launch_conv(n->pool1, p1, w.rowseg, R, dt, s))) return rc;
+  if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, w.pooled, dt, s))) return rc;
+  // unfolded tail: bnpool (statistics over the B utterances) -> linear -> bnembed        dynamictdnn.py:664-665
+  if ((rc = launch_bn_rows(w.pooled, 2 * n->ccatp, B, n->bn_pool, momentum, s))) return rc;
+  if ((rc = launch_tail(n->tail_raw, w.pooled, B, w.tailpart, w.embpre, 0, s))) return rc;
+  if ((rc = launch_bn_rows(w.embpre, n->embed, B, n->bn_embed, momentum, s))) return rc;
+  if (d_emb) SUGAR_HIP(hipMemcpyAsync(d_emb, w.embpre, (size_t)B * n->embed * 4, hipMemcpyDeviceToDevice, s));
+  return SUGAR_OK;
+}
+
+// the BN layers in the order of the C-ABI's `bn_index`: 0 layer1; 1 + 9 i + {0 first, 1..7 res2 step, 8 last};
+// 1 + 9 depth: bnpool; 2 + 9 depth: bnembed
+static BNState* bn_by_index(SugarSubnet* n, int idx, ConvLayer** conv) {
+  *conv = nullptr;
+  if (idx == 0) { *conv = &n->layer1; return &n->bn_layer1; }
+  const int last = 1 + 9 * n->depth;
+  if (idx == last) return &n->bn_pool;
+  if (idx == last + 1) return &n->bn_embed;
+  if (idx < 0 || idx > last + 1) return nullptr;
+  Block& b = n->blocks[(idx - 1) / 9];
+  const int k = (idx - 1) % 9;
+  if (k == 0) { *conv = &b.first; return &b.bn_first; }
+  if (k == 8) { *conv = &b.last; return &b.bn_last; }
+  *conv = &b.res[k - 1];
+  return &b.bn_res[k - 1];
+}
+
+static int bn_download(const BNState& st, std::vector<float> out[4]) {
+  std::vector<float> packed(4 * (size_t)st.n);
+  SUGAR_HIP(hipMemcpy(packed.data(), st.p, packed.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; ++k) {
+    out[k].resize(st.c);
+    for (int o = 0; o < st.c; ++o) out[k][o] = packed[(size_t)k * st.n + st.h_map[o]];
+  }
   return SUGAR_OK;
 }
 
@@ -428,6 +584,82 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
   hipStream_t s = (hipStream_t)stream;
   { Prof p(SUGAR_STAGE_FBANK, s); if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, w.logmel, w.feats, net->dtype, s))) return rc; }
   return tdnn_forward(net, w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
+}
+
+int sugar_tdnn_recalibrate(SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R, int t_max,
+                           void* d_workspace, int64_t workspace_bytes, float momentum, float* d_emb, void* stream) {
+  float dummy;
+  int rc = check_fwd_args(net, d_feats, d_row_off, B, R, t_max, d_workspace, workspace_bytes, d_emb ? d_emb : &dummy);
+  if (rc) return rc;
+  SUGAR_CHECK_ARG(momentum >= 0.f && momentum <= 1.f, "recalibrate: momentum %g outside [0, 1]", momentum);
+  SUGAR_CHECK_ARG(B > 1, "recalibrate: train-mode BatchNorm needs more than one utterance per batch");
+  const Workspace w = plan(net, B, R, d_workspace);
+  return tdnn_recalibrate(net, d_feats, d_row_off, B, R, t_max, w, momentum, d_emb, (hipStream_t)stream);
+}
+
+int sugar_embed_recalibrate(SugarSubnet* net, const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
+                            const int32_t* d_row_off, int B, int64_t R, int t_max, void* d_workspace,
+                            int64_t workspace_bytes, float momentum, float* d_emb, void* stream) {
+  float dummy;
+  int rc = check_fwd_args(net, d_wav, d_row_off, B, R, t_max, d_workspace, workspace_bytes, d_emb ? d_emb : &dummy);
+  if (rc) return rc;
+  SUGAR_CHECK_ARG(d_wav_off && d_wav_len, "embed_recalibrate: null pointer");
+  SUGAR_CHECK_ARG(momentum >= 0.f && momentum <= 1.f, "recalibrate: momentum %g outside [0, 1]", momentum);
+  SUGAR_CHECK_ARG(B > 1, "recalibrate: train-mode BatchNorm needs more than one utterance per batch");
+  const Workspace w = plan(net, B, R, d_workspace);
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, w.logmel, w.feats, net->dtype, s))) return rc;
+  return tdnn_recalibrate(net, w.feats, d_row_off, B, R, t_max, w, momentum, d_emb, s);
+}
+
+int sugar_subnet_bn_count(const SugarSubnet* net) { return net ? 3 + 9 * net->depth : SUGAR_EINVAL; }
+
+int sugar_subnet_bn_read(SugarSubnet* net, int bn_index, float* h_mean, float* h_var, int n) {
+  SUGAR_CHECK_ARG(net && h_mean && h_var, "bn_read: null pointer");
+  ConvLayer* conv;
+  BNState* st = bn_by_index(net, bn_index, &conv);
+  SUGAR_CHECK_ARG(st && st->p, "bn_read: no BatchNorm %d", bn_index);
+  SUGAR_CHECK_ARG(n == st->c, "bn_read: BatchNorm %d has %d channels, buffers hold %d", bn_index, st->c, n);
+  SUGAR_HIP(hipSetDevice(net->device));
+  SUGAR_HIP(hipDeviceSynchronize());
+  std::vector<float> v[4];
+  int rc = bn_download(*st, v);
+  if (rc) return rc;
+  memcpy(h_mean, v[2].data(), (size_t)n * sizeof(float));
+  memcpy(h_var, v[3].data(), (size_t)n * sizeof(float));
+  return SUGAR_OK;
+}
+
+int sugar_subnet_bn_reset(SugarSubnet* net) {
+  SUGAR_CHECK_ARG(net, "bn_reset: null pointer");
+  SUGAR_HIP(hipSetDevice(net->device));
+  for (int i = 0; i < sugar_subnet_bn_count(net); ++i) {
+    ConvLayer* conv;
+    BNState* st = bn_by_index(net, i, &conv);
+    std::vector<float> mv(2 * (size_t)st->n, 0.f);
+    for (int k = 0; k < st->n; ++k) mv[(size_t)st->n + k] = 1.f;          // nn.BatchNorm1d.reset_running_stats
+    SUGAR_HIP(hipMemcpy(st->mean(), mv.data(), mv.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return SUGAR_OK;
+}
+
+int sugar_subnet_bn_commit(SugarSubnet* net) {
+  SUGAR_CHECK_ARG(net, "bn_commit: null pointer");
+  SUGAR_HIP(hipSetDevice(net->device));
+  SUGAR_HIP(hipDeviceSynchronize());
+  int rc;
+  for (int i = 0; i < sugar_subnet_bn_count(net) - 2; ++i) {
+    ConvLayer* conv;
+    BNState* st = bn_by_index(net, i, &conv);
+    if ((rc = launch_bn_fold(*st, conv->scale, conv->shift, nullptr))) return rc;
+  }
+  std::vector<float> p[4], e[4];
+  if ((rc = bn_download(net->bn_pool, p)) || (rc = bn_download(net->bn_embed, e))) return rc;
+  const float* const pool_bn[4] = {p[0].data(), p[1].data(), p[2].data(), p[3].data()};
+  const float* const embed_bn[4] = {e[0].data(), e[1].data(), e[2].data(), e[3].data()};
+  if ((rc = fold_tail(net, pool_bn, embed_bn))) return rc;
+  SUGAR_HIP(hipDeviceSynchronize());
+  return SUGAR_OK;
 }
 
 int sugar_tdnn_tap(const SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R, int t_max,

@@ -132,6 +132,8 @@ class TDNNSubnet(nn.Module):
         self._handles = {}       # (device index, dtype) -> c_void_p
         self._workspace = {}     # device index -> torch.uint8 tensor
         self._device = torch.device("cpu")
+        self._bn_dirty = None    # (device index, dtype) of the handle holding recalibrated, not yet synced statistics
+        self._bn_batches = 0
         # parameters changed (also via a parent's load_state_dict) -> drop the packed device copies
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.release())
         self.eval()
@@ -174,6 +176,7 @@ class TDNNSubnet(nn.Module):
         for h in self._handles.values():
             _lib.lib().sugar_subnet_destroy(h)
         self._handles = {}
+        self._bn_dirty, self._bn_batches = None, 0
 
     def __del__(self):
         try:
@@ -256,15 +259,94 @@ class TDNNSubnet(nn.Module):
         return self.forward_rows(feats, row_off, B, B * T, T)
 
     def forward_rows(self, feats, row_off, B, R, t_max, normalize=False):
-        """feats: [R, 80] channels-last rows in the subnet's dtype; row_off: int32 [B+1] on the device."""
+        """feats: [R, 80] channels-last rows in the subnet's dtype; row_off: int32 [B+1] on the device.
+        In train() mode this is one BN-recalibration step (batch statistics, running statistics updated)."""
         dev = feats.device
         ws = self.workspace(dev, B, R)
         emb = torch.empty(B, self.out_embeds, dtype=torch.float32, device=dev)
-        rc = _lib.lib().sugar_tdnn_fwd(self.handle(dev), feats.data_ptr(), row_off.data_ptr(), B, R, t_max,
-                                       ws.data_ptr(), ws.numel(), emb.data_ptr(), int(normalize),
-                                       torch.cuda.current_stream(dev).cuda_stream)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.training:
+            rc = _lib.lib().sugar_tdnn_recalibrate(self.handle(dev), feats.data_ptr(), row_off.data_ptr(), B, R, t_max,
+                                                   ws.data_ptr(), ws.numel(), float(self.bn_momentum), emb.data_ptr(),
+                                                   stream)
+            _lib.check(rc, "sugar_tdnn_recalibrate")
+            self.mark_recalibrated(dev)
+            if normalize:
+                _lib.check(_lib.lib().sugar_l2norm(emb.data_ptr(), B, self.out_embeds, stream), "sugar_l2norm")
+            return emb
+        rc = _lib.lib().sugar_tdnn_fwd(self.eval_handle(dev), feats.data_ptr(), row_off.data_ptr(), B, R, t_max,
+                                       ws.data_ptr(), ws.numel(), emb.data_ptr(), int(normalize), stream)
         _lib.check(rc, "sugar_tdnn_fwd")
         return emb
+
+    # ---- BN recalibration (batch_forward, sugar/models/__init__.py:201-242) ------------------------------------
+    bn_momentum = 0.1        # nn.BatchNorm1d default, as DynamicBatchNorm1d builds it (dynamicarch.py:248)
+
+    def bn_names(self):
+        """BatchNorm prefixes in the order of the C-ABI's bn_index (include/sugar_amd.h)."""
+        names = ["layer1.bn"]
+        for i in range(self.subnet_config[0]):
+            p = "blocks.%d." % i
+            names += [p + "first_conv.bn"] + [p + "resconv.convs.%d.bn" % j for j in range(SCALE - 1)] + [p + "last_conv.bn"]
+        return names + ["bnpool", "bnembed"]
+
+    def mark_recalibrated(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, self.dtype_id)
+        if self._bn_dirty not in (None, key):
+            raise _lib.SugarError("BN recalibration is in progress on another device / precision: call sync_bn() first")
+        self._bn_dirty = key
+        self._bn_batches += 1
+
+    def sync_bn(self):
+        """Fold the recalibrated running statistics into the eval path and copy them into this module's buffers
+        (what `model.eval()` / `bn_state_dict` see in the reference).  No-op when nothing was recalibrated."""
+        if self._bn_dirty is None:
+            return self
+        key, self._bn_dirty = self._bn_dirty, None
+        h = self._handles[key]
+        _lib.check(_lib.lib().sugar_subnet_bn_commit(h), "sugar_subnet_bn_commit")
+        buffers = dict(self.named_buffers())
+        params = dict(self.named_parameters())
+        for i, name in enumerate(self.bn_names()):
+            rm = buffers.get(name + ".running_mean", params.get(name + ".running_mean"))
+            rv = buffers.get(name + ".running_var", params.get(name + ".running_var"))
+            m = torch.empty(rm.numel(), dtype=torch.float32)
+            v = torch.empty(rv.numel(), dtype=torch.float32)
+            _lib.check(_lib.lib().sugar_subnet_bn_read(h, i, _lib.fptr(m), _lib.fptr(v), m.numel()), "sugar_subnet_bn_read")
+            with torch.no_grad():
+                rm.copy_(m)
+                rv.copy_(v)
+                nbt = buffers.get(name + ".num_batches_tracked", params.get(name + ".num_batches_tracked"))
+                if nbt is not None:
+                    nbt.add_(self._bn_batches)
+        self._bn_batches = 0
+        for k in [k for k in self._handles if k != key]:        # other devices / precisions hold stale statistics
+            _lib.lib().sugar_subnet_destroy(self._handles.pop(k))
+        return self
+
+    def reset_bn(self):
+        """nn.BatchNorm1d.reset_running_stats on every BN (running_mean 0, running_var 1, num_batches_tracked 0)."""
+        self._bn_dirty, self._bn_batches = None, 0
+        with torch.no_grad():
+            for k, t in list(self.named_buffers()) + list(self.named_parameters()):
+                if k.endswith("running_mean"):
+                    t.zero_()
+                elif k.endswith("running_var"):
+                    t.fill_(1)
+                elif k.endswith("num_batches_tracked"):
+                    t.zero_()
+        self.release()
+        return self
+
+    def eval_handle(self, device=None):
+        """Handle for the eval-mode entry points: recalibrated statistics are folded in first."""
+        self.sync_bn()
+        return self.handle(device)
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_bn()
+        return super().state_dict(*args, **kwargs)
 
     def tap(self, feats, row_off, B, R, t_max, what):
         """Parity tap (tests): returns (activation [rows, C] float32 in the internal layout, embeddings)."""
@@ -272,7 +354,7 @@ class TDNNSubnet(nn.Module):
         ws = self.workspace(dev, B, R)
         emb = torch.empty(B, self.out_embeds, dtype=torch.float32, device=dev)
         out = torch.empty(max(R, B) * 4096, dtype=torch.float32, device=dev)
-        c = _lib.check(_lib.lib().sugar_tdnn_tap(self.handle(dev), feats.data_ptr(), row_off.data_ptr(), B, R, t_max,
+        c = _lib.check(_lib.lib().sugar_tdnn_tap(self.eval_handle(dev), feats.data_ptr(), row_off.data_ptr(), B, R, t_max,
                                                  ws.data_ptr(), ws.numel(), what, out.data_ptr(), out.numel(),
                                                  emb.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                        "sugar_tdnn_tap")

@@ -40,7 +40,12 @@ class SpeakerModel(nn.Module):
 
     def _subnet(self):
         s = self.__S__
-        return s.active_subnet() if isinstance(s, DynamicTDNN) else s
+        if isinstance(s, DynamicTDNN):
+            if s.training:
+                raise _lib.SugarError("BN recalibration runs on a cloned subnet: use supernet.clone(config), as the "
+                                      "callers of batch_forward do (SubnetEvaluation.ipynb, train_vox2_veri.py:395)")
+            return s.active_subnet()
+        return s
 
     def embed_ragged(self, wavs, normalize=False):
         """List of 1-D float waveforms (any lengths > 256 samples) -> [len(wavs), 192]; one fused C-ABI call."""
@@ -58,7 +63,18 @@ class SpeakerModel(nn.Module):
         dev = flat.device
         ws = sub.workspace(dev, plan.B, plan.R)
         emb = torch.empty(plan.B, sub.out_embeds, dtype=torch.float32, device=dev)
-        rc = _lib.lib().sugar_embed_fwd(sub.handle(dev), flat.data_ptr(), plan.wav_off.data_ptr(),
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if sub.training:          # one BN-recalibration step (batch_forward): batch statistics, running stats updated
+            rc = _lib.lib().sugar_embed_recalibrate(sub.handle(dev), flat.data_ptr(), plan.wav_off.data_ptr(),
+                                                    plan.wav_len.data_ptr(), plan.row_off.data_ptr(), plan.B, plan.R,
+                                                    plan.t_max, ws.data_ptr(), ws.numel(), float(sub.bn_momentum),
+                                                    emb.data_ptr(), stream)
+            _lib.check(rc, "sugar_embed_recalibrate")
+            sub.mark_recalibrated(dev)
+            if normalize:
+                _lib.check(_lib.lib().sugar_l2norm(emb.data_ptr(), plan.B, sub.out_embeds, stream), "sugar_l2norm")
+            return emb
+        rc = _lib.lib().sugar_embed_fwd(sub.eval_handle(dev), flat.data_ptr(), plan.wav_off.data_ptr(),
                                         plan.wav_len.data_ptr(), plan.row_off.data_ptr(), plan.B, plan.R, plan.t_max,
                                         ws.data_ptr(), ws.numel(), emb.data_ptr(), int(normalize),
                                         torch.cuda.current_stream(dev).cuda_stream)
@@ -196,3 +212,30 @@ def veri_validate(loader, model, args=None, tboard=None, norm=True, p_target=0.0
     if not ret_info:
         return eer, dcf
     return eer, dcf, vectors, scs
+
+
+def batch_forward(loader, model, args=None, device="cuda:0"):
+    """
+    BN recalibration (sugar/models/__init__.py:201-242): forward the model in train() mode over `loader` so every
+    BatchNorm of the cloned subnet re-estimates its running statistics, then restore the model's mode.  `loader`
+    yields batches whose first element is the waveform tensor [B, L] / [B, 1, L]; `args.gpu` selects the device as in
+    the reference.  The statistics are folded into the eval path (and copied into the module's buffers) on return.
+    """
+    if args is not None and getattr(args, "gpu", None) is not None:
+        device = "cuda:{}".format(args.gpu)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.SugarError("sugar_amd runs on an MI355X only: pass device='cuda:N' (there is no CPU fallback)")
+    origin_state = model.training
+    with torch.no_grad():
+        model.train()
+        model.to(dev)
+        for batch in loader:
+            inp = batch[0] if isinstance(batch, (list, tuple)) else batch
+            model.forward(inp.to(dev), None)
+        model.train(origin_state)
+    spk = model.module if hasattr(model, "module") else model
+    sub = getattr(spk, "__S__", None)
+    if isinstance(sub, TDNNSubnet):
+        sub.sync_bn()
+    return model

@@ -1,0 +1,105 @@
+"""
+BN recalibration (batch_forward, sugar/models/__init__.py:201-242).
+
+tests/golden/recal.npz holds what the REAL reference subnet produced (oracle/make_golden_recal.py): the running
+statistics of every BatchNorm after train()-mode forwards over seeded batches, the train-mode embeddings, and an
+eval() forward afterwards.  CPU: the oracle reproduces them.  GPU: sugar_amd.batch_forward through the C-ABI does.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sugar_amd
+from oracle import ref_cpu
+from oracle.make_golden_recal_inputs import CASES, EVAL_SEED, batches
+from sugar_amd import layout, synth
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "recal.npz"))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_train_mode_matches_reference(name):
+    cfg, B, L, nb = CASES[name]
+    osd = ref_cpu.clone_state(synth.fill_state_dict(layout.supernet_shapes(), seed=0), cfg)
+    for bi, wav in enumerate(batches(name, nb, B, L)):
+        e = ref_cpu.subnet_forward(osd, cfg[0], ref_cpu.logmel_fbank(wav).squeeze(1), train_momentum=0.1)
+        assert _rel(e.numpy(), GOLD["%s/train_emb%d" % (name, bi)]) < 1e-4
+    n = 0
+    for k in GOLD.files:
+        if k.startswith(name + "/") and (k.endswith("running_mean") or k.endswith("running_var")):
+            assert _rel(osd[k[len(name) + 1:]].numpy(), GOLD[k]) < 1e-5, k
+            n += 1
+    assert n == 2 * (3 + 9 * cfg[0])
+    e = ref_cpu.embed(osd, cfg[0], synth.waveforms(3, L, seed=EVAL_SEED))
+    assert _rel(e.numpy(), GOLD[name + "/eval_emb"]) < 1e-4
+
+
+class _Loader(list):
+    pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol_stat,tol_emb", [("fp32", 2e-4, 5e-4), ("bf16", 3e-2, 6e-2)])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_batch_forward_matches_reference(name, precision, tol_stat, tol_emb):
+    cfg, B, L, nb = CASES[name]
+    dev = torch.device("cuda", 0)
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    sub = sup.clone(cfg).set_precision(precision)
+    model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+    before = model(synth.waveforms(3, L, seed=EVAL_SEED).to(dev)).cpu().numpy()
+
+    # train()-mode forwards one by one: embeddings of each recalibration step
+    model.train()
+    for bi, wav in enumerate(batches(name, nb, B, L)):
+        e = model(wav.to(dev))
+        assert _rel(e.cpu().numpy(), GOLD["%s/train_emb%d" % (name, bi)]) < tol_emb
+    model.eval()
+    sd = sub.state_dict()                                  # syncs the statistics into the module's buffers
+    worst = 0.0
+    for k in GOLD.files:
+        if k.startswith(name + "/") and (k.endswith("running_mean") or k.endswith("running_var")):
+            worst = max(worst, _rel(sd[k[len(name) + 1:]].numpy(), GOLD[k]))
+    assert worst < tol_stat, worst
+    assert int(sd["layer1.bn.num_batches_tracked"]) == nb
+    after = model(synth.waveforms(3, L, seed=EVAL_SEED).to(dev)).cpu().numpy()
+    assert _rel(after, GOLD[name + "/eval_emb"]) < tol_emb
+    assert _rel(after, before) > 1e-3                      # the eval path really uses the new statistics
+
+    # the batch_forward call itself (fresh clone): same statistics, model mode restored
+    sub2 = sup.clone(cfg).set_precision(precision)
+    model2 = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub2, transform=sugar_amd.LogMelFbanks())).eval()
+    loader = _Loader((w, None) for w in batches(name, nb, B, L))
+    sugar_amd.batch_forward(loader, model2, device="cuda:0")
+    assert not model2.training
+    sd2 = sub2.state_dict()
+    for k in sd:
+        assert torch.equal(sd[k], sd2[k]), k               # deterministic: bit-identical statistics
+    bn = sugar_amd.bn_state_dict(sub2)
+    assert "layer1.bn.running_var" in bn
+
+
+@pytest.mark.gpu
+def test_reset_bn_and_errors():
+    dev = torch.device("cuda", 0)
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    sub = sup.clone(layout.SMALLEST).set_precision("fp32")
+    sub.reset_bn()
+    sd = sub.state_dict()
+    assert float(sd["bnembed.running_mean"].abs().max()) == 0.0 and float(sd["bnpool.running_var"].min()) == 1.0
+    model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev)
+    model.train()
+    with pytest.raises(ValueError):                        # torch: "Expected more than 1 value per channel"
+        model(synth.waveforms(1, 8000, seed=1).to(dev))
+    smodel = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sup, transform=sugar_amd.LogMelFbanks())).to(dev).train()
+    with pytest.raises(sugar_amd._lib.SugarError):         # supernet in train(): clone first
+        smodel(synth.waveforms(2, 8000, seed=1).to(dev))
