@@ -196,6 +196,24 @@ int sugar_cosine_trials(const float* d_vec, int dim, const int32_t* d_seg_off, i
                         const int32_t* d_enroll, const int32_t* d_test, int64_t n_trials,
                         float* d_scores, void* stream);
 
+/* ---- adaptive score normalisation back-end -----------------------------------------
+ * Replaces: score_cohorts (sugar/scores.py:77-111): d_out[u][m] = mean over utterance u's segment vectors of
+ * F.cosine_similarity(segment, cohort m) (eps 1e-8).  d_vec / d_seg_off as in sugar_cosine_trials,
+ * d_cohort float32 [n_cohort][dim], d_scratch float32 [(n_utts + n_cohort) * dim], d_out float32 [n_utts][n_cohort]. */
+int sugar_cohort_scores(const float* d_vec, int dim, const int32_t* d_seg_off, int n_utts, const float* d_cohort,
+                        int n_cohort, float* d_scratch, float* d_out, void* stream);
+/* Replaces: the "Cohort Statistics" loop of asnorm (sugar/scores.py:370-379; torch.topk(value, nTop) -> mean,
+ * sqrt(sum((v - mean)^2 / |nTop|))) and of snorm (:305-308; all values, divisor = number of trials, as written
+ * there).  Per row of d_scores [n_rows][n_cols]: the ntop largest (ntop < 0: the |ntop| smallest) values are
+ * selected exactly; d_mean[r] = their mean, d_std[r] = sqrt(sum((v - mean)^2) / divisor).  1 <= |ntop| <= n_cols. */
+int sugar_topk_stats(const float* d_scores, int64_t n_rows, int n_cols, int ntop, float divisor, float* d_mean,
+                     float* d_std, void* stream);
+/* Replaces: the "Normalization Statistics" loop + the final lines of asnorm / snorm (sugar/scores.py:388-399):
+ * d_out[t] = 0.5 * ((s - mean[e]) / max(std[e], std_eps) + (s - mean[u]) / max(std[u], std_eps)),
+ * e = d_enroll[t], u = d_test[t] row indices into d_mean / d_std. */
+int sugar_snorm_trials(const float* d_scores, const int32_t* d_enroll, const int32_t* d_test, int64_t n_trials,
+                       const float* d_mean, const float* d_std, float std_eps, float* d_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Live per-stage timing (bench.py's roofline figures).  No reference counterpart; the reference times whole
  * forwards with torch.cuda.synchronize (sugar/metrics.py:389-404).

@@ -321,3 +321,47 @@ def count_macs(config, T: int) -> float:
         macs += 2 * c0 * (w * SCALE) * T + 7 * w * w * ki * T + 2 * c0 * (c0 // SE_REDUCTION)
     macs += depth * c0 * ccat * T + 2 * ccat * BOTTLENECK * T + 2 * ccat * 192
     return float(macs)
+
+
+# --------------------------------------------------------------------------- score normalisation (8f rank 2)
+def score_cohorts(cohorts: torch.Tensor, vectors: dict) -> dict:
+    """score_cohorts (sugar/scores.py:77-111): per utterance, cosine of every segment vector with every cohort vector
+    (F.cosine_similarity broadcast), mean over the segments -> {utterance: float32 ndarray [n_cohort]}."""
+    out = {}
+    for k, vec in vectors.items():
+        out[k] = F.cosine_similarity(vec.unsqueeze(-1), cohorts.unsqueeze(-1).transpose(0, 2)).mean(0).numpy()
+    return out
+
+
+def asnorm(orig_scores, enrolls, tests, cohort: dict, ntop: int = 300, std_eps: float = 1e-8) -> np.ndarray:
+    """asnorm (sugar/scores.py:332-400): top-|ntop| cohort scores per utterance (ntop < 0: the smallest) ->
+    mean, sqrt(sum((v - m)^2 / |ntop|)); result 0.5 * (z-norm + t-norm) in float64."""
+    mean, std = {}, {}
+    for k, value in cohort.items():
+        v = np.sort(np.asarray(value))
+        v = v[:-ntop] if ntop < 0 else v[len(v) - ntop:]
+        m = v.mean()
+        mean[k] = m
+        std[k] = np.sum((v - m) ** 2 / abs(ntop)) ** 0.5
+    return _znorm_tnorm(orig_scores, enrolls, tests, mean, std, std_eps)
+
+
+def snorm(orig_scores, enrolls, tests, cohort: dict, std_eps: float = 1e-8) -> np.ndarray:
+    """snorm without nTop (sugar/scores.py:295-329): all cohort scores; the std divides by N = number of TRIALS,
+    as the reference does (:295, :308)."""
+    n = len(orig_scores)
+    mean, std = {}, {}
+    for k, value in cohort.items():
+        m = value.mean()
+        mean[k] = m
+        std[k] = np.sum((value - m) ** 2 / n) ** 0.5
+    return _znorm_tnorm(orig_scores, enrolls, tests, mean, std, std_eps)
+
+
+def _znorm_tnorm(orig_scores, enrolls, tests, mean, std, std_eps):
+    s = np.asarray(orig_scores, dtype=np.float64)
+    zm = np.array([mean[e] for e in enrolls], dtype=np.float64)
+    zs = np.array([max(std[e], std_eps) for e in enrolls], dtype=np.float64)
+    tm = np.array([mean[t] for t in tests], dtype=np.float64)
+    ts = np.array([max(std[t], std_eps) for t in tests], dtype=np.float64)
+    return 0.5 * ((s - zm) / zs + (s - tm) / ts)

@@ -8,11 +8,11 @@ from .dynamictdnn import (DynamicTDNN, TDNNPath, TDNNSubnet, ecapa_tdnn, specfic
                           tdnn16m4g, tdnn26m7g)
 from .metrics import calculate_eer, calculate_mindcf
 from .models import SpeakerModel, WrappedModel, batch_forward, bn_state_dict, checkpoint2backbone, veri_validate
-from .scores import calculate_score, score_trials
+from .scores import asnorm, calculate_score, score_cohorts, score_trials, snorm
 from .transforms import LogMelFbanks, PreEmphasis
 from .vectors import extract_vectors
 
 __all__ = ["DynamicTDNN", "TDNNPath", "TDNNSubnet", "ecapa_tdnn", "specfic_tdnn", "tdnn8m2g", "tdnn14m4g",
            "tdnn16m4g", "tdnn26m7g", "SpeakerModel", "WrappedModel", "bn_state_dict", "checkpoint2backbone",
            "calculate_score", "score_trials", "LogMelFbanks", "PreEmphasis", "extract_vectors", "veri_validate", "batch_forward",
-           "calculate_eer", "calculate_mindcf"]
+           "calculate_eer", "calculate_mindcf", "score_cohorts", "asnorm", "snorm"]

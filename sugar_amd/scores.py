@@ -69,3 +69,134 @@ def score_trials(trials, vectors, mode="cosine", n_jobs=4):
                          torch.tensor(e_idx, dtype=torch.int32, device=dev),
                          torch.tensor(t_idx, dtype=torch.int32, device=dev))
     return scores.double().cpu().numpy(), np.array(labels), pairs
+
+
+# ------------------------------------------------------------------------------------------------ score normalisation
+class CohortScores(dict):
+    """
+    What score_cohorts returns: {utterance: float32 ndarray [n_cohort]} like the reference (sugar/scores.py:96-111),
+    materialised lazily -- the [n_utts, n_cohort] matrix stays on the GPU (`.matrix`, rows in `.keys_order`) so that
+    asnorm / snorm run there without a 117 MB round trip; the first dict access copies it to the host once.
+    """
+
+    def __init__(self, keys, matrix):
+        super().__init__()
+        self.keys_order = list(keys)
+        self.matrix = matrix
+        self._host = False
+
+    def _materialise(self):
+        if not self._host:
+            self._host = True
+            host = self.matrix.cpu().numpy()
+            for i, k in enumerate(self.keys_order):
+                dict.__setitem__(self, k, host[i])
+
+    def __getitem__(self, k):
+        self._materialise()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def keys(self):
+        return list(self.keys_order)
+
+    def __iter__(self):
+        return iter(self.keys_order)
+
+    def __len__(self):
+        return len(self.keys_order)
+
+    def __contains__(self, k):
+        self._materialise()
+        return dict.__contains__(self, k)
+
+
+def score_cohorts(cohorts, vectors, mode="cosine", device="cuda:0"):
+    """
+    sugar/scores.py:77-111: for every utterance the mean (over its segment vectors) cosine similarity with each of the
+    cohort vectors.  cohorts: Tensor [n_cohort, D]; vectors: {utterance: Tensor [n_seg, D]}.
+    Returns a CohortScores dict {utterance: ndarray [n_cohort]}.
+    """
+    if mode != "cosine":
+        raise ValueError("only mode='cosine' is supported (as in the reference)")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.SugarError("sugar_amd runs on an MI355X only: pass device='cuda:N' (there is no CPU fallback)")
+    keys = list(vectors.keys())
+    seg = [0]
+    for k in keys:
+        seg.append(seg[-1] + vectors[k].reshape(-1, vectors[k].shape[-1]).shape[0])
+    vec = torch.cat([vectors[k].reshape(-1, vectors[k].shape[-1]).to(dev) for k in keys], dim=0).float().contiguous()
+    coh = cohorts.to(dev).float().contiguous()
+    n_utts, n_coh, dim = len(keys), coh.shape[0], vec.shape[1]
+    if coh.shape[1] != dim:
+        raise ValueError("cohort vectors have %d dimensions, utterance vectors %d" % (coh.shape[1], dim))
+    seg_off = torch.tensor(seg, dtype=torch.int32, device=dev)
+    scratch = torch.empty((n_utts + n_coh) * dim, dtype=torch.float32, device=dev)
+    out = torch.empty(n_utts, n_coh, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().sugar_cohort_scores(vec.data_ptr(), dim, seg_off.data_ptr(), n_utts, coh.data_ptr(), n_coh,
+                                             scratch.data_ptr(), out.data_ptr(), _stream(dev)), "sugar_cohort_scores")
+    return CohortScores(keys, out)
+
+
+def _cohort_matrix(cohort, device):
+    if isinstance(cohort, CohortScores):
+        return cohort.keys_order, cohort.matrix
+    keys = list(cohort.keys())
+    mat = torch.from_numpy(np.stack([np.asarray(cohort[k], dtype=np.float32) for k in keys])).to(device)
+    return keys, mat.contiguous()
+
+
+def _trial_columns(scores):
+    """scores: DataFrame (or mapping) with columns score / enroll / test, as in the reference."""
+    return (np.asarray(scores["score"], dtype=np.float64), list(scores["enroll"]), list(scores["test"]))
+
+
+def _snorm_gpu(scores, cohort, ntop, divisor, std_eps, device):
+    orig, enr, tst = _trial_columns(scores)
+    dev = torch.device(device)
+    keys, mat = _cohort_matrix(cohort, dev)
+    index = {k: i for i, k in enumerate(keys)}
+    n_rows, n_cols = mat.shape
+    mean = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    std = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    st = _stream(dev)
+    _lib.check(_lib.lib().sugar_topk_stats(mat.data_ptr(), n_rows, n_cols, int(ntop), float(divisor), mean.data_ptr(),
+                                          std.data_ptr(), st), "sugar_topk_stats")
+    s = torch.from_numpy(orig.astype(np.float32)).to(dev)
+    e = torch.tensor([index[k] for k in enr], dtype=torch.int32, device=dev)
+    t = torch.tensor([index[k] for k in tst], dtype=torch.int32, device=dev)
+    out = torch.empty(len(orig), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().sugar_snorm_trials(s.data_ptr(), e.data_ptr(), t.data_ptr(), len(orig), mean.data_ptr(),
+                                            std.data_ptr(), float(std_eps), out.data_ptr(), st), "sugar_snorm_trials")
+    return out.double().cpu().numpy()
+
+
+def asnorm(scores, cohort, nTop=300, std_eps=1e-8, device="cuda:0"):
+    """
+    Adaptive s-norm (sugar/scores.py:332-400): per utterance, mean / std of its nTop most similar cohort scores
+    (nTop < 0: the |nTop| least similar); every trial score becomes the average of its z-norm (enrol statistics)
+    and t-norm (test statistics).  scores: DataFrame with columns score / enroll / test; cohort: score_cohorts'
+    return value (or any {utterance: ndarray}).  Returns a float64 ndarray.
+    """
+    return _snorm_gpu(scores, cohort, nTop, abs(nTop), std_eps, device)
+
+
+def snorm(scores, cohort, nTop=None, std_eps=1e-8, device="cuda:0"):
+    """
+    S-norm (sugar/scores.py:269-329).  nTop given -> asnorm.  Otherwise all cohort scores are used and the standard
+    deviation is sqrt(sum((v - mean)^2) / N) with N = the number of TRIALS, exactly as the reference computes it
+    (:295, :308).
+    """
+    if nTop is not None:
+        return asnorm(scores, cohort, nTop, std_eps, device)
+    n_trials = len(_trial_columns(scores)[0])
+    keys, mat = _cohort_matrix(cohort, torch.device(device))
+    return _snorm_gpu(scores, cohort, mat.shape[1], n_trials, std_eps, device)
