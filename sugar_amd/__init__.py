@@ -6,6 +6,7 @@ and its checkpoint format; all device work is hand-written gfx950 HIP behind the
 """
 from .dynamictdnn import (DynamicTDNN, TDNNPath, TDNNSubnet, ecapa_tdnn, specfic_tdnn, tdnn8m2g, tdnn14m4g,
                           tdnn16m4g, tdnn26m7g)
+from .latency import TDNNLatency, latency
 from .metrics import calculate_eer, calculate_mindcf
 from .models import SpeakerModel, WrappedModel, batch_forward, bn_state_dict, checkpoint2backbone, veri_validate
 from .scores import asnorm, calculate_score, score_cohorts, score_trials, snorm
@@ -15,4 +16,4 @@ from .vectors import extract_vectors
 __all__ = ["DynamicTDNN", "TDNNPath", "TDNNSubnet", "ecapa_tdnn", "specfic_tdnn", "tdnn8m2g", "tdnn14m4g",
            "tdnn16m4g", "tdnn26m7g", "SpeakerModel", "WrappedModel", "bn_state_dict", "checkpoint2backbone",
            "calculate_score", "score_trials", "LogMelFbanks", "PreEmphasis", "extract_vectors", "veri_validate", "batch_forward",
-           "calculate_eer", "calculate_mindcf", "score_cohorts", "asnorm", "snorm"]
+           "calculate_eer", "calculate_mindcf", "score_cohorts", "asnorm", "snorm", "TDNNLatency", "latency"]
