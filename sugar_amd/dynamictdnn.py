@@ -130,7 +130,7 @@ class TDNNSubnet(nn.Module):
         shapes = layout.subnet_shapes(self.subnet_config, in_feats, out_embeds)
         _build_tree(self, shapes, _default_init if state is None else (lambda k, s: state[k].detach().clone()))
         self._handles = {}       # (device index, dtype) -> c_void_p
-        self._workspace = {}     # device index -> torch.uint8 tensor
+        self._workspace = {}     # (device index, stream) -> torch.uint8 tensor
         self._device = torch.device("cpu")
         self._bn_dirty = None    # (device index, dtype) of the handle holding recalibrated, not yet synced statistics
         self._bn_batches = 0
@@ -233,9 +233,11 @@ class TDNNSubnet(nn.Module):
     def workspace(self, device, B, R):
         need = _lib.check(_lib.lib().sugar_workspace_bytes(self.handle(device), B, R), "sugar_workspace_bytes")
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        ws = self._workspace.get(idx)
+        # one workspace per (device, stream): forwards issued on different streams may overlap on the GPU
+        key = (idx, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspace.get(key)
         if ws is None or ws.numel() < need:
-            self._workspace[idx] = ws = torch.empty(int(need * 1.05) + 256, dtype=torch.uint8, device=device)
+            self._workspace[key] = ws = torch.empty(int(need * 1.05) + 256, dtype=torch.uint8, device=device)
         return ws
 
     # ---- internal channel layout (for parity taps) ----------------------------------------------------------

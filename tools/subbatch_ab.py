@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B: one 256-utterance pass vs the same utterances in sub-batches (working set vs the 256 MB Infinity Cache)."""
+"""A/B: one 256-utterance pass vs the same utterances as sub-batches, sequentially or on concurrent HIP streams
+(memory-bound kernels of one sub-batch under the MFMA-bound kernels of another)."""
 import os
 import sys
 import time
@@ -13,20 +14,34 @@ from sugar_amd import layout, synth  # noqa: E402
 dev = torch.device("cuda", 0)
 sup = sugar_amd.tdnn8m2g()
 sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
-sub = sup.clone(layout.BASE).set_precision("bf16")
-model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+
+
+def make():
+    sub = sup.clone(layout.BASE).set_precision("bf16")
+    return sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+
+
 wav = torch.randn(256, 48000, device=dev)
 for rep in range(2):
-    for chunk in (256, 128, 96, 64, 32):
-        parts = [wav[i:i + chunk].contiguous() for i in range(0, 256, chunk)]
+    for nstreams, chunk in ((1, 256), (2, 128), (2, 256), (3, 256), (4, 256)):
+        models = [make() for _ in range(nstreams)]           # one workspace per stream
+        streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+        total = 256 if chunk != 256 else 256 * nstreams
+        src = torch.cat([wav] * (total // 256))
+        parts = [src[i:i + chunk].contiguous() for i in range(0, total, chunk)]
+
+        def run():
+            for i, p in enumerate(parts):
+                with torch.cuda.stream(streams[i % nstreams]):
+                    models[i % nstreams](p, normalize=True)
+
         for _ in range(3):
-            for p in parts:
-                model(p, normalize=True)
+            run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(20):
-            for p in parts:
-                model(p, normalize=True)
+            run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 20
-        print("chunk %3d: %.3f ms per 256 utterances  (%.0f emb/s)" % (chunk, dt * 1e3, 256 / dt), flush=True)
+        print("streams %d chunk %3d: %.3f ms per %d utterances  (%.0f emb/s)" % (nstreams, chunk, dt * 1e3, total,
+                                                                               total / dt), flush=True)
