@@ -113,6 +113,13 @@ struct ConvIO {
 
 int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s);
 
+// Tap conv (dilation 1, bf16) as an LDS-DMA GEMM over overlapping rows of a zero-padded copy of x (conv1x1.hip):
+// d_xpad must hold gemm_taps_pad_rows(L, B, R) rows of L.cin_p elements.
+bool gemm_taps_eligible(const ConvLayer& L, int ldx, int dtype);
+int64_t gemm_taps_pad_rows(const ConvLayer& L, int B, int64_t R);
+int launch_gemm_taps(const ConvLayer& L, const void* d_x, void* d_xpad, void* d_y, int ldy, const int32_t* d_row_off,
+                     int B, int64_t R, int t_max, hipStream_t s);
+
 // Pack a reference-layout conv weight [cout][cin][k] (host f32) into ConvLayer storage with an internal channel
 // permutation / padding: out_map[o] = packed output row of reference channel o, in_map[i] = packed input
 // column of reference input channel i (nullptr = identity).  bn may be nullptr.

@@ -37,6 +37,11 @@ struct Gemm1x1Args {
   int ldx, ldw, ldy, ldy2, y2_from;
   int R, cout, K, flags;
   int n_co_tiles;
+  // tap convs as a GEMM over overlapping rows (layer1): the activation buffer holds every utterance with `xmap / 2`
+  // zero rows before and after it, so the K vector of output row r (taps t-h..t+h, channels-last) is the contiguous
+  // run starting at padded row r + xmap * b(r), b = utterance of r (found from row_off).  xmap = 0: plain rows.
+  const int32_t* row_off = nullptr;
+  int B = 0, xmap = 0;
 };
 
 constexpr int TK = 64;
@@ -78,7 +83,15 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
   for (int i = 0; i < XI; ++i) {
     const int row = wv * (XI * 8) + i * 8 + srow;
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    const int xr = min(r_base + row, a.R - 1);                // rows past R: any valid row, masked at the store
+    int xr = min(r_base + row, a.R - 1);                      // rows past R: any valid row, masked at the store
+    if (a.xmap) {                                             // utterance index: last b with row_off[b] <= xr
+      int lo = 0, hi = a.B;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.row_off[mid] <= xr) lo = mid; else hi = mid;
+      }
+      xr += a.xmap * lo;
+    }
     xsrc[i] = a.x + (size_t)xr * a.ldx + chunk * 8;
   }
   auto stage = [&](int buf, int kt) {
@@ -263,7 +276,59 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
   return SUGAR_OK;
 }
 
+// dst[(r + 2 h b + h)][C] = src[r][C] for the rows of utterance b (16 bytes per thread), zeros in the h rows before
+// and after it; the last utterance's workgroups also zero the `slack` rows that close the buffer
+__global__ __launch_bounds__(256) void pad_rows_kernel(const bf16* __restrict__ src, int C, const int32_t* __restrict__ row_off,
+                                                       int halo, int slack, bf16* __restrict__ dst) {
+  const int b = blockIdx.y;
+  const int s0 = row_off[b], n = row_off[b + 1] - s0;
+  const int nch = C >> 3;
+  const int64_t first = (int64_t)s0 + (int64_t)2 * halo * b;          // padded row of the leading halo
+  const int rows = n + 2 * halo + (b == (int)gridDim.y - 1 ? slack : 0);
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < rows * nch; it += gridDim.x * 256) {
+    const int r = it / nch, ch = it - r * nch, t = r - halo;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t >= 0 && t < n) v = *(const u32x4*)(src + ((int64_t)s0 + t) * C + ch * 8);
+    *(u32x4*)(dst + (first + r) * C + ch * 8) = v;
+  }
+}
+
 }  // namespace
+
+// ---- tap conv (dilation 1) as a GEMM over overlapping rows of a zero-padded copy of the activations ---------------
+// layer1 (80 mel bins, 5 taps: K = 400) is 4 % of the MACs but ran at a tenth of the GEMM rate through the generic
+// masked-load kernel; its K vector is contiguous in a channels-last buffer, so the LDS-DMA GEMM can read it in place.
+bool gemm_taps_eligible(const ConvLayer& L, int ldx, int dtype) {
+  return dtype == SUGAR_BF16 && L.dil == 1 && L.ktaps > 1 && ldx == L.cin_p && L.cin_p % 8 == 0 && L.k_pad % TK == 0 &&
+         L.n_pad % 128 == 0 && L.cout > 64 && L.cout % 8 == 0 && !(L.flags & EPI_TANH);
+}
+
+int64_t gemm_taps_pad_rows(const ConvLayer& L, int B, int64_t R) {
+  const int halo = (L.ktaps - 1) / 2;
+  // + slack: the last row's K vector is read up to k_pad elements (zero weights beyond ktaps * cin_p)
+  return R + (int64_t)2 * halo * B + ceil_div(L.k_pad, L.cin_p) + 1;
+}
+
+int launch_gemm_taps(const ConvLayer& L, const void* d_x, void* d_xpad, void* d_y, int ldy, const int32_t* d_row_off,
+                     int B, int64_t R, int t_max, hipStream_t s) {
+  const int halo = (L.ktaps - 1) / 2, C = L.cin_p;
+  SUGAR_CHECK_ARG(((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_xpad & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && ldy % 8 == 0,
+                  "gemm_taps: unaligned buffers");
+  const int slack = (int)(gemm_taps_pad_rows(L, B, R) - R - (int64_t)2 * halo * B);
+  const int64_t items = (int64_t)(t_max + 2 * halo + slack) * (C >> 3);
+  const unsigned gx = (unsigned)(ceil_div(items, 256) < 64 ? ceil_div(items, 256) : 64);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, (const bf16*)d_x, C, d_row_off, halo, slack,
+                     (bf16*)d_xpad);
+  SUGAR_LAUNCH_CHECK();
+  Gemm1x1Args a;
+  a.x = (const bf16*)d_xpad; a.w = (const bf16*)L.w; a.y = (bf16*)d_y; a.y2 = nullptr;
+  a.scale = L.scale; a.shift = L.shift;
+  a.ldx = C; a.ldw = L.k_pad; a.ldy = ldy; a.ldy2 = 0; a.y2_from = 0;
+  a.R = (int)R; a.cout = L.cout; a.K = L.k_pad; a.flags = L.flags;
+  a.n_co_tiles = (int)ceil_div(L.cout, 128);
+  a.row_off = d_row_off; a.B = B; a.xmap = 2 * halo;
+  return launch_variant<128, 128, 2>(a, s);
+}
 
 // Eligibility: bf16, single tap, no addend, K tile-aligned, weight rows padded to the channel tile.
 bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype) {

@@ -284,7 +284,7 @@ static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
 struct Workspace {
   int2* rowseg;
   float* logmel;
-  void *feats, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
+  void *feats, *featp, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
   float *semean, *sescale, *pooled, *tailpart;
   double* bnpart;    // recalibration: partial sums, batch (scale, shift), pre-BN embeddings
   float *bnscale, *bnshift, *embpre;
@@ -303,6 +303,7 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   w.rowseg = (int2*)take(R * (int64_t)sizeof(int2));
   w.logmel = (float*)take(R * SUGAR_N_MELS * 4);
   w.feats = take(R * SUGAR_N_MELS * esz);
+  w.featp = take(gemm_taps_pad_rows(n->layer1, B, R) * n->in_feats * esz);   // zero-padded copy for the layer1 GEMM
   w.S = take(R * n->c0p * esz);
   w.cat = take(R * (int64_t)n->depth * n->c0p * esz);
   w.mid1 = take(R * n->midp_max * esz);
@@ -338,7 +339,15 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
 
   ConvIO io;
   io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
-  { Prof p(SUGAR_STAGE_LAYER1, s); if ((rc = launch_conv(n->layer1, io, w.rowseg, R, dt, s))) return rc; }
+  {
+    Prof p(SUGAR_STAGE_LAYER1, s);
+    static const bool generic_l1 = getenv("SUGAR_GENERIC_LAYER1") != nullptr;   // A/B switch for the parity tests
+    if (!generic_l1 && gemm_taps_eligible(n->layer1, n->in_feats, dt))
+      rc = launch_gemm_taps(n->layer1, feats, w.featp, w.S, n->c0p, row_off, B, R, t_max, s);
+    else
+      rc = launch_conv(n->layer1, io, w.rowseg, R, dt, s);
+    if (rc) return rc;
+  }
   if ((rc = tapcopy(0, w.S, n->c0p, n->c0p))) return rc;
 
   const int ldcat = n->depth * n->c0p;
