@@ -46,6 +46,18 @@ struct Gemm1x1Args {
 
 constexpr int TK = 64;
 
+// Diagnostic build only (tools/gemm_variants.hip with -DGEMM_STAMPS): shader-clock stamps of waves 0 and 4 of one
+// workgroup around the phases of the ping-pong loop; the library build compiles none of this.
+#ifdef GEMM_STAMPS
+__device__ long long* g_gemm_stamps;
+#define GEMM_STAMP()                                                                                    \
+  do {                                                                                                  \
+    if (stamp_on && kt >= 4 && kt < 7) { stamp_buf[stamp_n] = (long long)__builtin_amdgcn_s_memtime(); ++stamp_n; } \
+  } while (0)
+#else
+#define GEMM_STAMP() do {} while (0)
+#endif
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -54,7 +66,7 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 }
 
 // One TM x TN output tile at (co_base, r_base), by the whole 512-thread workgroup.
-template <int TM, int TN, int NS>
+template <int TM, int TN, int NS, int PP = 0>
 __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_base, const int r_base) {
   constexpr int STAGE_BYTES = (TM + TN) * 128;
   constexpr int MI = TM / 32;                    // 16-channel MFMA tiles per wave
@@ -66,7 +78,7 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
   constexpr int EPI_STRIDE = CW * 2 + 16;        // bytes per staged output row
   constexpr int HN = NJ >= 2 ? 2 : 1;            // frame tiles per epilogue pass
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;
 
   // ---- DMA addressing: each wave fills its rows of both operand tiles, 8 rows (1 KiB) per instruction ----------
@@ -107,6 +119,17 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
                                        (__attribute__((address_space(3))) void*)(xbase + i * 1024), 16, 0, 0);
   };
 
+  auto dma_one = [&](int buf, int kt, int i) {        // instruction i of stage(): 0..WI-1 weights, then activations
+    unsigned char* wbase = smem + buf * STAGE_BYTES + wv * (WI * 8) * 128;
+    unsigned char* xbase = smem + buf * STAGE_BYTES + TM * 128 + wv * (XI * 8) * 128;
+    if (i < WI)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * TK),
+                                       (__attribute__((address_space(3))) void*)(wbase + i * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i - WI] + kt * TK),
+                                       (__attribute__((address_space(3))) void*)(xbase + (i - WI) * 1024), 16, 0, 0);
+  };
+
   f32x4 acc[MI][NJ];
 #pragma unroll
   for (int m = 0; m < MI; ++m)
@@ -134,6 +157,76 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
   // NS-stage ring: k-tile t+D (D = NS-1) is issued right after the barrier that opens k-tile t, into the buffer
   // k-tile t-1 was read from
   constexpr int D = NS - 1, NDMA = WI + XI;
+  if constexpr (PP) {
+    // ---- ping-pong schedule (NS == 2) ---------------------------------------------------------------------------
+    // The two waves of a SIMD (wm = 0 / 1: hardware places wave w on SIMD w % 4) alternate: while one reads its 12
+    // fragments of a 32-deep half k-tile from LDS, the other issues the 32 MFMAs of the half it read one phase
+    // earlier.  Every phase ends in a workgroup barrier; group 1 runs one phase behind group 0.  Phase numbering
+    // p (group 0): 4 kt + 2 h = read (kt, h), + 1 = MFMA; group 1 does the same at p + 1.  Buffer (kt+1) % 2 was
+    // last read in phase 4 kt - 1, so the DMA of k-tile kt + 1 is issued in each group's read phase of (kt, 0) and
+    // drained (vmcnt) before the barrier that closes phase 4 kt + 3, after which group 0 reads it.
+    static_assert(!PP || NS == 2, "ping-pong needs the two-stage ring");
+#ifdef GEMM_STAMPS
+    const bool stamp_on = g_gemm_stamps && lane == 0 && (wv == 0 || wv == 4) && blockIdx.x == 8;
+    long long* stamp_buf = g_gemm_stamps + (wv ? 1 : 0) * 64;
+    int stamp_n = 0;
+#endif
+    // PP == 1: the DMA of k-tile kt + 1 is issued at the top of each group's read phase of (kt, 0).
+    // PP == 2: it is issued one instruction per MFMA row inside an MFMA phase, where the VMEM issue slots are idle
+    //          (in-kernel stamps: 8 DMA instructions at the top of a read phase stretch it from ~370 to ~860 clocks,
+    //          past the ~660 of the other group's MFMA phase): group 0 in its MFMA phase of (kt, 0) = phase 4 kt + 1,
+    //          group 1 in its MFMA phase of (kt - 1, 1) = phase 4 kt, the first phase in which that buffer is free.
+    static_assert(PP != 2 || WI + XI <= MI, "one DMA instruction per MFMA row");
+    stage(0, 0);
+    if (PP == 2 && wm && nk > 1) {
+      stage(1, 1);                                                 // group 1's share of k-tile 1 has no earlier MFMA phase
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");
+    if (wm) asm volatile("s_barrier" ::: "memory");               // group 1 idles through phase 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* wb = smem + (kt & 1) * STAGE_BYTES;
+      const unsigned char* xb = wb + TM * 128;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[MI], bf[NJ];
+        GEMM_STAMP();                                              // A: read phase opens
+        if (PP == 1 && s == 0 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) af[m] = *(const bf16x8*)(wb + swz(wm * CW + m * 16 + fr, 4 * s + fq));
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) bf[n] = *(const bf16x8*)(xb + swz(wn * FW + n * 16 + fr, 4 * s + fq));
+        if (s == 1 && wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GEMM_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GEMM_STAMP();                                              // B: fragments have arrived
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP();                                              // C: MFMA phase opens
+        const int tk = wm ? kt + 2 : kt + 1;                       // k-tile this wave stages during this MFMA phase
+        const bool issue = PP == 2 && s == (wm ? 1 : 0) && tk < nk;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+#pragma unroll
+          for (int n = 0; n < NJ; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+          if (PP == 2) {
+            if (m < NDMA && issue) dma_one(tk & 1, tk, m);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP();                                              // D: MFMAs issued
+        if (s == 1 && !wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // group 1's last MFMA phase needs no closing barrier: nobody reads LDS after phase 4 nk - 1, so both groups
+        // execute the same number of barriers and each goes to its epilogue straight away
+        if (!(wm && s == 1 && kt + 1 == nk)) asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < D; ++t)
     if (t < nk) stage(t, t);
@@ -162,6 +255,7 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
     nxt = nxt + 1 == NS ? 0 : nxt + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage memory becomes the epilogue staging
+  }
 
   // ---- epilogue --------------------------------------------------------------------------------------------
   // accumulator tile (m, n): lane (fr, fq) holds frame wn*FW + n*16 + fr, channels wm*CW + m*16 + 4 fq + {0..3}
@@ -217,10 +311,10 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
 }
 
 // Uniform grid: every workgroup one TM x TN tile.
-template <int TM, int TN, int NS>
+template <int TM, int TN, int NS, int PP = 0>
 __global__ __launch_bounds__(512, TM == 256 ? 2 : 4) void gemm1x1_kernel(Gemm1x1Args a) {
   const int vid = xcd_remap2(blockIdx.x, gridDim.x);
-  gemm_tile<TM, TN, NS>(a, (vid % a.n_co_tiles) * TM, (vid / a.n_co_tiles) * TN);
+  gemm_tile<TM, TN, NS, PP>(a, (vid % a.n_co_tiles) * TM, (vid / a.n_co_tiles) * TN);
 }
 
 // Split-tail grid for the wide convs.  With one 256 x 256 tile per CU at a time the makespan is ceil(tiles / CUs)
@@ -229,36 +323,37 @@ __global__ __launch_bounds__(512, TM == 256 ? 2 : 4) void gemm1x1_kernel(Gemm1x1
 // along the frames into `split` (1, 2 or 4) sub-tiles with their own wave tiling, so the last round fills the chip
 // with pieces that take 1/2 or 1/4 of a round.  Same outputs bit for bit: every output element still sums its K
 // products in the same order.
-template <int NS>
+template <int NS, int PP = 0>
 __global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, int n_main, int split) {
   const int bid = blockIdx.x;
   if (bid < n_main) {
     const int vid = xcd_remap2(bid, n_main);
-    gemm_tile<256, 256, NS>(a, (vid % a.n_co_tiles) * 256, (vid / a.n_co_tiles) * 256);
+    gemm_tile<256, 256, NS, PP>(a, (vid % a.n_co_tiles) * 256, (vid / a.n_co_tiles) * 256);
     return;
   }
   const int t = bid - n_main;
   const int tile = n_main + t / split, sub = t - (t / split) * split;
   const int co_base = (tile % a.n_co_tiles) * 256, r_tile = (tile / a.n_co_tiles) * 256;
-  if (split == 4) gemm_tile<256, 64, NS>(a, co_base, r_tile + sub * 64);
-  else if (split == 2) gemm_tile<256, 128, NS>(a, co_base, r_tile + sub * 128);
-  else gemm_tile<256, 256, NS>(a, co_base, r_tile);
+  if (split == 4) gemm_tile<256, 64, NS, PP>(a, co_base, r_tile + sub * 64);
+  else if (split == 2) gemm_tile<256, 128, NS, PP>(a, co_base, r_tile + sub * 128);
+  else gemm_tile<256, 256, NS, PP>(a, co_base, r_tile);
 }
 
-template <int TM, int TN, int NS>
+template <int TM, int TN, int NS, int PP = 0>
 int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = NS * (TM + TN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    SUGAR_HIP(hipFuncSetAttribute((const void*)gemm1x1_kernel<TM, TN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    SUGAR_HIP(hipFuncSetAttribute((const void*)gemm1x1_kernel<TM, TN, NS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int grid = a.n_co_tiles * (int)ceil_div(a.R, TN);
-  hipLaunchKernelGGL((gemm1x1_kernel<TM, TN, NS>), dim3(grid), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((gemm1x1_kernel<TM, TN, NS, PP>), dim3(grid), dim3(512), smem, s, a);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
 
+template <int PP = 0>
 int launch_split(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = 2 * (256 + 256) * 128;
   static int n_cu = 0;
@@ -266,12 +361,12 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
     int dev = 0;
     SUGAR_HIP(hipGetDevice(&dev));
     SUGAR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    SUGAR_HIP(hipFuncSetAttribute((const void*)gemm1x1_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    SUGAR_HIP(hipFuncSetAttribute((const void*)gemm1x1_split_kernel<2, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   }
   const int total = a.n_co_tiles * (int)ceil_div(a.R, 256);
   const int n_main = total / n_cu * n_cu, tail = total - n_main;
   const int split = tail == 0 ? 1 : tail * 4 <= n_cu ? 4 : tail * 2 <= n_cu ? 2 : 1;
-  hipLaunchKernelGGL(gemm1x1_split_kernel<2>, dim3(n_main + tail * split), dim3(512), smem, s, a, n_main, split);
+  hipLaunchKernelGGL((gemm1x1_split_kernel<2, PP>), dim3(n_main + tail * split), dim3(512), smem, s, a, n_main, split);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
@@ -356,7 +451,9 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
     }
     a.n_co_tiles = (int)ceil_div(L.cout, 256);
     static const bool uniform = getenv("SUGAR_GEMM_UNIFORM") != nullptr;   // A/B switch: no split tail
-    return uniform ? launch_variant<256, 256, 2>(a, s) : launch_split(a, s);
+    static const bool no_pp = getenv("SUGAR_GEMM_NO_PINGPONG") != nullptr;   // A/B switch: both waves of a SIMD in step
+    if (uniform) return launch_variant<256, 256, 2>(a, s);
+    return no_pp ? launch_split<0>(a, s) : launch_split<1>(a, s);
   }
   a.n_co_tiles = 1;
   return launch_variant<128, 64, 3>(a, s);

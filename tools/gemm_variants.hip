@@ -89,6 +89,33 @@ int main(int argc, char** argv) {
   a.n_co_tiles = N / 128; launch_variant<128, 128, 2>(a, 0); check("<128,128,2>");
   a.n_co_tiles = N / 128; launch_variant<128, 256, 2>(a, 0); check("<128,256,2>");
   a.n_co_tiles = N / 256; launch_variant<256, 128, 2>(a, 0); check("<256,128,2>");
+  a.n_co_tiles = N / 256; launch_variant<256, 256, 2, true>(a, 0); check("<256,256,2> pp");
+  a.n_co_tiles = N / 256; launch_split<true>(a, 0); check("split pp");
+  a.n_co_tiles = N / 256; launch_variant<256, 256, 2, 2>(a, 0); check("<256,256,2> pp2");
+  a.n_co_tiles = N / 256; launch_split<2>(a, 0); check("split pp2");
+  a.n_co_tiles = N / 128; launch_variant<128, 128, 2, 2>(a, 0); check("<128,128,2> pp2");
+  a.n_co_tiles = N / 128; launch_variant<128, 128, 2, true>(a, 0); check("<128,128,2> pp");
+#ifdef GEMM_STAMPS
+  {
+    long long* stamps;
+    CK(hipMalloc(&stamps, 2 * 64 * 8));
+    CK(hipMemset(stamps, 0, 2 * 64 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(sugar::g_gemm_stamps), &stamps, sizeof(stamps)));
+    a.n_co_tiles = N / 256;
+    launch_variant<256, 256, 2, GEMM_STAMPS>(a, 0);
+    CK(hipDeviceSynchronize());
+    long long h[128];
+    CK(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
+    long long* null_ptr = nullptr;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(sugar::g_gemm_stamps), &null_ptr, sizeof(null_ptr)));
+    // 4 stamps (A read opens, B fragments in, C MFMA opens, D MFMAs issued) per half k-tile, k-tiles 4..6
+    for (int w = 0; w < 2; ++w) {
+      printf("stamps wave %d (ticks since first; A B C D per half k-tile):\n", w * 4);
+      for (int i = 0; i < 24; ++i) printf("%s%6lld", i % 4 == 0 ? "\n   " : " ", h[w * 64 + i] - h[0]);
+      printf("\n");
+    }
+  }
+#endif
   for (int round = 0; round < 4; ++round) {
     if (round == 2) CK(hipMalloc(&g_flush, 1u << 30));
     printf("round %d  R=%d N=%d K=%d %s\n", round, R, N, K, g_flush ? "COLD (caches flushed before every launch)" : "warm");
@@ -97,7 +124,13 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_variant<256, 256, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<256,256,2>", t, flop / t / 1e9);
     t = timeit([&] { launch_split(a, 0); }, 10);                printf("  %-18s %.4f ms  %.0f TF\n", "split", t, flop / t / 1e9);
     t = timeit([&] { launch_variant<256, 128, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<256,128,2>", t, flop / t / 1e9);
+    t = timeit([&] { launch_variant<256, 256, 2, true>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<256,256,2> pp", t, flop / t / 1e9);
+    t = timeit([&] { launch_split<true>(a, 0); }, 10);                printf("  %-18s %.4f ms  %.0f TF\n", "split pp", t, flop / t / 1e9);
+    t = timeit([&] { launch_variant<256, 256, 2, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<256,256,2> pp2", t, flop / t / 1e9);
+    t = timeit([&] { launch_split<2>(a, 0); }, 10);                printf("  %-18s %.4f ms  %.0f TF\n", "split pp2", t, flop / t / 1e9);
     a.n_co_tiles = N / 128;
+    t = timeit([&] { launch_variant<128, 128, 2, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,128,2> pp2", t, flop / t / 1e9);
+    t = timeit([&] { launch_variant<128, 128, 2, true>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,128,2> pp", t, flop / t / 1e9);
     t = timeit([&] { launch_variant<128, 128, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,128,2> 2WG/CU", t, flop / t / 1e9);
     t = timeit([&] { launch_variant<128, 256, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,256,2>", t, flop / t / 1e9);
     t = timeit([&] { launch_variant<128, 128, 3>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,128,3>", t, flop / t / 1e9);
