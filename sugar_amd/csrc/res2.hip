@@ -16,7 +16,11 @@
 //     output slice and adds the x_{j+1} chunks (prefetched one step ahead in the same layout) to form u_{j+1}.
 //     In-kernel stamps showed the earlier 8-byte-per-lane loads/stores in MFMA layout (16 half-used lines per
 //     instruction, 37 vector-memory instructions per wave and step) spent 60 % of every step in memory issue.
-// Utterances longer than 640 frames (or f32) take the generic per-step path in conv_gemm.hip.
+// Utterances longer than the 384 frames one workgroup holds are cut into time segments, one workgroup each: a segment
+// processes its frames plus H = 7 * halo context frames on every side that is not a true utterance end.  Treating the
+// clipped side as zero padding corrupts sp_j within (j + 1) * halo frames of it, i.e. never inside the stored range,
+// so the outputs equal the unsegmented chain bit for bit (the context frames are recomputed: +17 % work at halo 4).
+// f32 takes the generic per-step path in conv_gemm.hip.
 #include <stdlib.h>
 
 #include "common.h"
@@ -24,9 +28,9 @@
 namespace sugar {
 namespace {
 
-constexpr int R2_TPW_MAX = 5;        // frame tiles (of 16) per wave: 3 (T <= 384) or 5 (T <= 640)
+constexpr int R2_TPW_MAX = 3;        // frame tiles (of 16) per wave
 constexpr int R2_WAVES = 8;
-constexpr int R2_MAX_T = 16 * R2_TPW_MAX * R2_WAVES;   // 640 frames
+constexpr int R2_MAX_T = 16 * R2_TPW_MAX * R2_WAVES;   // 384 frames per workgroup (segment incl. its context)
 constexpr int R2_STEPS = SUGAR_RES2_SCALE - 1;
 
 struct Res2Args {
@@ -37,6 +41,8 @@ struct Res2Args {
   const float* shift[R2_STEPS];
   const int32_t* row_off;
   int ld, wp, ktaps, dil, k_pad;
+  int max_t;         // frames one workgroup processes: R2_MAX_T (the parity tests lower it to force segments)
+  int seg_inner;     // most stored frames per segment (multiple of 16): max_t - 2 * 7 * halo
 };
 
 // Diagnostic build only (tools/res2_bench.hip defines R2_STAMPS): shader-clock stamps of wave 0 / wave 7 of two
@@ -66,7 +72,17 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NI = (MT + 1) / 2;                      // 16-byte chunk items per lane and frame tile
   const int b = blockIdx.x;
-  const int s0 = a.row_off[b], T = a.row_off[b + 1] - s0;
+  const int wp = a.wp, ctr = (a.ktaps - 1) >> 1, halo = ctr * a.dil;
+  // segment blockIdx.y of utterance b: stored frames [t0, t1), processed frames [p0, p1) of the utterance
+  const int u0 = a.row_off[b], Tu = a.row_off[b + 1] - u0;
+  const int nseg = Tu <= a.max_t ? 1 : (Tu + a.seg_inner - 1) / a.seg_inner;
+  if ((int)blockIdx.y >= nseg) return;
+  const int inner = nseg == 1 ? Tu : (((Tu + nseg - 1) / nseg + 15) & ~15);
+  const int t0 = blockIdx.y * inner, t1 = min(Tu, t0 + inner);
+  if (t0 >= t1) return;
+  const int ctx = R2_STEPS * halo;
+  const int p0 = max(0, t0 - ctx), p1 = min(Tu, t1 + ctx);
+  const int s0 = u0 + p0, T = p1 - p0, st_lo = t0 - p0, st_hi = t1 - p0;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int f = lane & 15, q = lane >> 4;
 #ifdef R2_STAMPS
@@ -75,7 +91,6 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   int stamp_n = 0;
 #endif
   R2_STAMP();
-  const int wp = a.wp, ctr = (a.ktaps - 1) >> 1, halo = ctr * a.dil;
   const int NT = (T + 15) >> 4;
   const int urow = wp * 2;                              // bytes per u row
   const int nch = wp >> 3;                              // 16-byte chunks per u row
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
         const u32x4 sp = *(const u32x4*)(ot + ooff[i]);
         if (item_ok(n, i)) {
           const int r = (wv + R2_WAVES * n) * 16 + irow[i];
-          *(u32x4*)(yb + r * a.ld + j * wp + ich[i] * 8) = sp;
+          if (r >= st_lo && r < st_hi) *(u32x4*)(yb + r * a.ld + j * wp + ich[i] * 8) = sp;
           if (!last) xs[(j + 1) & 1][n][i] = add_bf16x8(xs[(j + 1) & 1][n][i], sp);
         }
       }
@@ -302,15 +317,16 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
 }
 
 int r2_smem_bytes(int t_max, int wp, int halo, int k_pad) {
+  t_max = t_max < R2_MAX_T ? t_max : R2_MAX_T;
   const int u_rows = (t_max + 15) / 16 * 16 + 2 * halo;
-  const int ot = t_max <= 16 * 3 * R2_WAVES ? 3 : 1;    // sp staging tiles per wave (kernel: OT)
+  const int ot = 3;                                     // sp staging tiles per wave (kernel: OT)
   return ((u_rows * wp * 2 + 255) & ~255) + 64 * k_pad * 2 + R2_WAVES * ot * 16 * wp * 2 + R2_STEPS * 128 * 4;
 }
 
 }  // namespace
 
 bool res2_chain_eligible(int dtype, int t_max, int wp, int k_pad, int n_pad) {
-  if (dtype != SUGAR_BF16 || t_max > R2_MAX_T || wp > 64 || wp % 8 != 0 || n_pad != 64) return false;
+  if (dtype != SUGAR_BF16 || t_max < 1 || wp > 64 || wp % 8 != 0 || n_pad != 64) return false;
   if (getenv("SUGAR_GENERIC_RES2")) return false;   // A/B switch for the parity tests: force the per-step path
   return k_pad <= 64 * 5 && r2_smem_bytes(t_max, wp, 10, k_pad) <= 160 * 1024;
 }
@@ -326,12 +342,23 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
     a.w[j] = (const bf16*)steps[j].w; a.scale[j] = steps[j].scale; a.shift[j] = steps[j].shift;
   }
   const int halo = ((a.ktaps - 1) / 2) * a.dil;
-  SUGAR_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && (int64_t)t_max * ld < (1ll << 31),
+  a.max_t = R2_MAX_T;
+  if (const char* e = getenv("SUGAR_RES2_MAX_T")) {      // parity tests: segment utterances the kernel could hold whole
+    const int v = atoi(e);
+    if (v >= 128 && v <= R2_MAX_T) a.max_t = v & ~15;
+  }
+  a.seg_inner = (a.max_t - 2 * R2_STEPS * halo) & ~15;
+  if (a.seg_inner < 16) {                                // override too small for this halo: ignore it
+    a.max_t = R2_MAX_T;
+    a.seg_inner = (a.max_t - 2 * R2_STEPS * halo) & ~15;
+  }
+  SUGAR_CHECK_ARG(a.seg_inner >= 16, "res2: halo %d leaves no room for time segments", halo);
+  const int nseg_max = t_max <= a.max_t ? 1 : (int)ceil_div(t_max, a.seg_inner);
+  SUGAR_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && (int64_t)R2_MAX_T * ld < (1ll << 31),
                   "res2: activations must be 16-byte aligned with ld %% 8 == 0 (ld %d)", ld);
   const int smem = r2_smem_bytes(t_max, wp, halo, a.k_pad);
   SUGAR_CHECK_ARG(smem <= 160 * 1024 && a.k_pad <= 320, "res2: tile does not fit LDS (%d bytes)", smem);
   const int mt = (wp + 15) / 16;
-  const bool small = t_max <= 16 * 3 * R2_WAVES;        // 3 frame tiles per wave cover 384 frames
   const bool w3 = a.k_pad <= 192;
 #define R2_CASE(M, TP, WR)                                                                                     \
   {                                                                                                            \
@@ -341,19 +368,15 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
       attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR>), dim3(B), dim3(512), smem, s, a);                        \
+    hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR>), dim3(B, nseg_max), dim3(512), smem, s, a);                        \
   }
 #define R2_CASE_W(M, TP) \
   if (w3) R2_CASE(M, TP, 3) else R2_CASE(M, TP, 5)
-  switch (mt * 2 + (small ? 0 : 1)) {
-    case 2: R2_CASE_W(1, 3) break;
-    case 3: R2_CASE_W(1, 5) break;
-    case 4: R2_CASE_W(2, 3) break;
-    case 5: R2_CASE_W(2, 5) break;
-    case 6: R2_CASE_W(3, 3) break;
-    case 7: R2_CASE_W(3, 5) break;
-    case 8: R2_CASE_W(4, 3) break;
-    default: R2_CASE_W(4, 5) break;
+  switch (mt) {
+    case 1: R2_CASE_W(1, 3) break;
+    case 2: R2_CASE_W(2, 3) break;
+    case 3: R2_CASE_W(3, 3) break;
+    default: R2_CASE_W(4, 3) break;
   }
 #undef R2_CASE_W
 #undef R2_CASE

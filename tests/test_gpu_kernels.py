@@ -224,8 +224,8 @@ def test_fused_res2_chain_matches_per_step_path_bf16(name, meta, supernet):
     cfg = cfg_of(meta, name)
     sub = supernet.clone(cfg).set_precision("bf16")
     supernet.config = None
-    # <= 384 frames: 3 tiles per wave; "largest"/"odd" also run the 5-tile variant (385..640 frames)
-    frames = [301, 63, 17, 130] if name not in ("largest", "odd") else [640, 385, 16, 500]
+    # <= 384 frames: one workgroup per utterance; "largest"/"odd" also run time-segmented utterances
+    frames = [301, 63, 17, 130] if name not in ("largest", "odd") else [640, 385, 16, 1500]
     R = sum(frames)
     feats = synth.normal("res2/feats", (R, 80), seed=4).to(torch.bfloat16).to(DEV)
     row_off = torch.tensor(_row_off(frames), dtype=torch.int32, device=DEV)
@@ -249,3 +249,31 @@ def test_fused_res2_chain_matches_per_step_path_bf16(name, meta, supernet):
         assert rel < 1.5e-2, (name, i, rel)
     cos = F.cosine_similarity(outs["fused"][-1].double(), outs["generic"][-1].double(), dim=1)
     assert cos.min() > 0.9995
+
+
+@pytest.mark.parametrize("name", ["base", "largest", "odd"])
+def test_res2_time_segments_are_bit_identical(name, meta, supernet):
+    """Utterances cut into time segments with 7 * halo context frames (res2.hip) give exactly the bytes of the chain
+    run over the whole utterance in one workgroup: SUGAR_RES2_MAX_T lowers the per-workgroup capacity so that
+    utterances the kernel can hold whole (<= 384 frames) are segmented, and both runs use the same fused kernel."""
+    import os
+    cfg = cfg_of(meta, name)
+    sub = supernet.clone(cfg).set_precision("bf16")
+    supernet.config = None
+    frames = [384, 301, 129, 16, 383, 200]
+    R = sum(frames)
+    feats = synth.normal("res2seg/feats", (R, 80), seed=5).to(torch.bfloat16).to(DEV)
+    row_off = torch.tensor(_row_off(frames), dtype=torch.int32, device=DEV)
+    depth = cfg[0]
+    outs = {}
+    for cap in (None, "256", "160"):
+        if cap:
+            os.environ["SUGAR_RES2_MAX_T"] = cap
+        try:
+            outs[cap] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
+            outs[cap].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
+        finally:
+            os.environ.pop("SUGAR_RES2_MAX_T", None)
+    for cap in ("256", "160"):
+        for i in range(depth + 1):
+            assert torch.equal(outs[None][i], outs[cap][i]), (name, cap, i)
