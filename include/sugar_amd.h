@@ -113,11 +113,13 @@ int64_t sugar_workspace_bytes(const SugarSubnet* net, int B, int64_t R);
  * + 1e-6, log (:70-72) + InstanceNorm1d(80) (:47,73), as one fused DFT kernel plus a per-utterance normaliser.
  *   d_wav      float32 samples of all utterances; utterance b = d_wav[wav_off[b] .. wav_off[b]+wav_len[b])
  *   d_row_off  int32[B+1] frame offsets, row_off[b+1]-row_off[b] must equal 1 + wav_len[b]/160
- *   d_logmel   float32 [R][80] scratch (log mel before normalisation)
+ *   d_logmel   float32 scratch of sugar_fbank_scratch_bytes(B, R): [R][80] log mel before normalisation, followed by
+ *              the per-chunk statistics of utterances longer than 320 frames
  *   d_feats    dtype   [R][80] output, channels-last (the reference returns [B,1,80,T])
- *   t_max      max frames of any utterance (grid sizing) */
+ *   R          total frames = row_off[B];  t_max  max frames of any utterance (grid sizing) */
+int64_t sugar_fbank_scratch_bytes(int B, int64_t R);
 int sugar_fbank_fwd(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
-                    const int32_t* d_row_off, int B, int t_max,
+                    const int32_t* d_row_off, int B, int64_t R, int t_max,
                     float* d_logmel, void* d_feats, int dtype, void* stream);
 
 /* Replaces: DynamicTDNN.forward on a cloned subnet (dynamictdnn.py:645-666) [+ F.normalize(p=2) of

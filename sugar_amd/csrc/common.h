@@ -133,8 +133,10 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
                       int B, int t_max, hipStream_t s);
 
 // ---- front-end (fbank.hip) ----------------------------------------------------------------------
+// d_logmel: fbank_scratch_floats(B, R) floats = [R][80] log-mel rows + the chunk statistics of long utterances
+int64_t fbank_scratch_floats(int B, int64_t R);
 int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
-                 int B, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s);
+                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s);
 
 // ---- SE / pooling / tail (se_pool.hip) ----------------------------------------------------------
 struct SELayer {            // device, f32, transposed for coalesced reads
@@ -156,8 +158,11 @@ struct PoolLayer {
   int ccat = 0, ccat_p = 0, bott = 0;
 };
 // attentive statistics: pooled[b] = [mean(ccat_p) | std(ccat_p)] (f32)
+// d_part: pool_part_floats(P, B, R) floats, the segment table of utterances longer than 1024 frames
+int64_t pool_part_floats(const PoolLayer& P, int B, int64_t R);
 int launch_pool_stats(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh,
-                      const int32_t* d_row_off, int B, float* d_pooled, int dtype, hipStream_t s);
+                      const int32_t* d_row_off, int B, int t_max, float* d_pooled, float* d_part, int dtype,
+                      hipStream_t s);
 
 struct TailLayer {          // folded bnpool . linear . bnembed, f32
   float* wt = nullptr;      // [2*ccat_p][embed]

@@ -324,6 +324,100 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float*
   for (int r = rl + NORM_LANES * NORM_CACHE; r < n; r += NORM_LANES)
     dst[(size_t)r * NMEL] = from_f32<T>((src[(size_t)r * NMEL] - mean) * inv);
 }
+
+// ---- utterances longer than NORM_LANES * NORM_CACHE = 320 frames: chunks of 320 frames, one workgroup each ----------
+// One workgroup per utterance is a serial loop over the frames (60 s of audio: 750 dependent trips per lane, 0.38 ms
+// for 16 utterances).  Chunk statistics (mean_c, M2_c = sum (x - mean_c)^2, both from registers exactly as above) go
+// to a small table; every chunk's apply workgroup merges the table of its utterance (Chan et al.:
+// M2 = sum M2_c + n_c (mean_c - mean)^2) and normalises its rows.  An utterance of one chunk merges to exactly the
+// numbers of instnorm_kernel, so an utterance's features do not depend on what else is in the batch.
+constexpr int NORM_CHUNK = NORM_LANES * NORM_CACHE;
+
+__device__ __forceinline__ int norm_slot(const int32_t* row_off, int b) { return row_off[b] / NORM_CHUNK + b; }
+
+__global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_stats_kernel(const float* __restrict__ logmel,
+                                                                           const int32_t* __restrict__ row_off,
+                                                                           float* __restrict__ part) {
+  __shared__ float red[NORM_LANES][NMEL];
+  const int b = blockIdx.y, c = blockIdx.x;
+  const int s = row_off[b], nu = row_off[b + 1] - s;
+  const int r0 = c * NORM_CHUNK;
+  if (r0 >= nu) return;
+  const int n = min(NORM_CHUNK, nu - r0);
+  const int m = threadIdx.x % NMEL, rl = threadIdx.x / NMEL;
+  const float* __restrict__ src = logmel + (size_t)(s + r0) * NMEL + m;
+  float vals[NORM_CACHE];
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) vals[i] = src[(size_t)min(rl + NORM_LANES * i, n - 1) * NMEL];
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) acc += (rl + NORM_LANES * i < n) ? vals[i] : 0.f;
+  red[rl][m] = acc;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_LANES; ++i) mean += red[i][m];
+  mean /= (float)n;
+  __syncthreads();
+  acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) {
+    const float d = (rl + NORM_LANES * i < n) ? vals[i] - mean : 0.f;
+    acc = fmaf(d, d, acc);
+  }
+  red[rl][m] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_LANES; ++i) m2 += red[i][m];
+    float* p = part + (size_t)(norm_slot(row_off, b) + c) * (2 * NMEL);
+    p[m] = mean;
+    p[NMEL + m] = m2;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_apply_kernel(const float* __restrict__ logmel,
+                                                                           const int32_t* __restrict__ row_off,
+                                                                           const float* __restrict__ part,
+                                                                           T* __restrict__ feats) {
+  const int b = blockIdx.y, c = blockIdx.x;
+  const int s = row_off[b], nu = row_off[b + 1] - s;
+  const int r0 = c * NORM_CHUNK;
+  if (r0 >= nu) return;
+  const int n = min(NORM_CHUNK, nu - r0);
+  const int m = threadIdx.x % NMEL, rl = threadIdx.x / NMEL;
+  const float* __restrict__ src = logmel + (size_t)(s + r0) * NMEL + m;
+  float vals[NORM_CACHE];
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) vals[i] = src[(size_t)min(rl + NORM_LANES * i, n - 1) * NMEL];
+  const float* __restrict__ p = part + (size_t)norm_slot(row_off, b) * (2 * NMEL);
+  const int nc = (nu + NORM_CHUNK - 1) / NORM_CHUNK;
+  float mean, var;
+  if (nc == 1) {
+    mean = p[m];
+    var = p[NMEL + m] / (float)nu;
+  } else {
+    double sum = 0.0;
+    for (int k = 0; k < nc; ++k) sum += (double)min(NORM_CHUNK, nu - k * NORM_CHUNK) * (double)p[k * 2 * NMEL + m];
+    const double mu = sum / (double)nu;
+    double m2 = 0.0;
+    for (int k = 0; k < nc; ++k) {
+      const double d = (double)p[k * 2 * NMEL + m] - mu;
+      m2 += (double)p[k * 2 * NMEL + NMEL + m] + (double)min(NORM_CHUNK, nu - k * NORM_CHUNK) * d * d;
+    }
+    mean = (float)mu;
+    var = (float)(m2 / (double)nu);                    // biased, as InstanceNorm1d
+  }
+  const float inv = 1.0f / sqrtf(var + 1e-5f);
+  T* __restrict__ dst = feats + (size_t)(s + r0) * NMEL + m;
+#pragma unroll
+  for (int i = 0; i < NORM_CACHE; ++i) {
+    const int r = rl + NORM_LANES * i;
+    if (r < n) dst[(size_t)r * NMEL] = from_f32<T>((vals[i] - mean) * inv);
+  }
+}
 }  // namespace
 
 int fbank_init() {
@@ -331,10 +425,12 @@ int fbank_init() {
   return get_tables(&t);
 }
 
+int64_t fbank_scratch_floats(int B, int64_t R) { return R * NMEL + (R / NORM_CHUNK + B + 1) * (2 * NMEL); }
+
 int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
-                 int B, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s) {
+                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s) {
   SUGAR_CHECK_ARG(d_wav && d_wav_off && d_wav_len && d_row_off && d_logmel && d_feats, "fbank: null pointer");
-  SUGAR_CHECK_ARG(B > 0 && B <= 65535 && t_max > 0, "fbank: bad batch %d / t_max %d", B, t_max);
+  SUGAR_CHECK_ARG(B > 0 && B <= 65535 && t_max > 0 && R >= t_max, "fbank: bad batch %d / t_max %d / R %lld", B, t_max, (long long)R);
   SUGAR_CHECK_ARG(dtype == SUGAR_F32 || dtype == SUGAR_BF16, "fbank: bad dtype %d", dtype);
   FbankTables tb;
   int rc = get_tables(&tb);
@@ -342,6 +438,20 @@ int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_
   hipLaunchKernelGGL(fbank_fft_kernel, dim3((unsigned)ceil_div(t_max, FRAMES), (unsigned)B), dim3(256), 0, s, d_wav,
                      d_wav_off, d_wav_len, d_row_off, tb, d_logmel);
   SUGAR_LAUNCH_CHECK();
+  if (t_max > NORM_CHUNK) {
+    float* part = d_logmel + R * NMEL;                  // chunk statistics live behind the log-mel rows
+    const dim3 grid((unsigned)ceil_div(t_max, NORM_CHUNK), (unsigned)B);
+    hipLaunchKernelGGL(instnorm_stats_kernel, grid, dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off, part);
+    SUGAR_LAUNCH_CHECK();
+    if (dtype == SUGAR_F32)
+      hipLaunchKernelGGL(instnorm_apply_kernel<float>, grid, dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off, part,
+                         (float*)d_feats);
+    else
+      hipLaunchKernelGGL(instnorm_apply_kernel<bf16>, grid, dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off, part,
+                         (bf16*)d_feats);
+    SUGAR_LAUNCH_CHECK();
+    return SUGAR_OK;
+  }
   if (dtype == SUGAR_F32)
     hipLaunchKernelGGL(instnorm_kernel<float>, dim3((unsigned)B), dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off,
                        (float*)d_feats);

@@ -10,6 +10,12 @@
 // One workgroup = 8 waves = (utterance, 256 channels).  Per 32-frame tile the a tile [32 x 128] and the h tile
 // [32 x 256] are staged through LDS with 16-byte coalesced loads (register prefetch of tile t+1 during tile t, two LDS
 // buffers, one barrier per tile); chunk index XOR (row & 15) keeps the ds_read_b128 fragment reads conflict-free.
+//
+// Utterances longer than POOL_SEG = 1024 frames are cut into segments of 1024 frames, one workgroup each (a 60 s
+// utterance is a serial loop of 188 tiles otherwise, and a batch of 16 of them fills a third of the chip): a segment
+// leaves its online-softmax state (max, sum p, sum p h, sum p h^2) in a table and pool_merge_kernel folds the
+// segments of an utterance in order.  The segment length is fixed, so an utterance's statistics do not depend on
+// what else is in the batch; utterances of one segment are finished by the main kernel as before.
 #include "common.h"
 
 namespace sugar {
@@ -40,12 +46,15 @@ struct PoolMma<float> {
 constexpr int PT = 32;     // frames per tile
 constexpr int PC = 256;    // channels per workgroup
 constexpr int BOTT = 128;
+constexpr int POOL_SEG = 1024;   // frames per time segment (multiple of PT)
+
+__device__ __forceinline__ int pool_slot(const int32_t* row_off, int b) { return row_off[b] / POOL_SEG + b; }
 
 template <typename T>
 __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel(const T* __restrict__ a, int lda, const T* __restrict__ h,
                                                          int ldh, const T* __restrict__ w2, int ccat_p,
                                                          const int32_t* __restrict__ row_off,
-                                                         float* __restrict__ pooled) {
+                                                         float* __restrict__ pooled, float* __restrict__ part) {
   constexpr int E = PoolMma<T>::E;
   constexpr int NG = PoolMma<T>::NG;
   constexpr int A_CH = BOTT / E;                 // 16-byte chunks per a row   (16 bf16 / 32 f32)
@@ -58,7 +67,10 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x (a tile | h tile)
 
   const int b = blockIdx.y;
-  const int s = row_off[b], n = row_off[b + 1] - s;
+  const int s_utt = row_off[b], n_utt = row_off[b + 1] - s_utt;
+  const int seg0 = blockIdx.z * POOL_SEG;
+  if (seg0 >= n_utt) return;
+  const int s = s_utt + seg0, n = min(POOL_SEG, n_utt - seg0);   // this workgroup's frames
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int c_base = blockIdx.x * PC;
@@ -155,6 +167,13 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
   l = l * f1 + l2 * f2;
   s1 = s1 * f1 + s12 * f2;
   s2 = s2 * f1 + s22 * f2;
+  if (n_utt > POOL_SEG) {                          // one of several segments: leave the state to pool_merge_kernel
+    if (fh == 0 && co_ok) {
+      float* p = part + (size_t)(pool_slot(row_off, b) + blockIdx.z) * 4 * ccat_p + co;
+      p[0] = M; p[ccat_p] = l; p[2 * ccat_p] = s1; p[3 * ccat_p] = s2;
+    }
+    return;
+  }
   if (fh == 0 && co_ok) {
     const float mean = s1 / l;
     const float var = s2 / l - mean * mean;
@@ -163,33 +182,65 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
   }
 }
 
+__global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict__ part, int ccat_p,
+                                                         const int32_t* __restrict__ row_off, float* __restrict__ pooled) {
+  const int b = blockIdx.y, co = blockIdx.x * 256 + threadIdx.x;
+  const int n = row_off[b + 1] - row_off[b];
+  if (n <= POOL_SEG || co >= ccat_p) return;
+  const int nseg = (n + POOL_SEG - 1) / POOL_SEG;
+  const float* p = part + (size_t)pool_slot(row_off, b) * 4 * ccat_p + co;
+  float m = p[0], l = p[ccat_p], s1 = p[2 * ccat_p], s2 = p[3 * ccat_p];
+  for (int k = 1; k < nseg; ++k) {
+    const float* q = p + (size_t)k * 4 * ccat_p;
+    const float m2 = q[0], M = fmaxf(m, m2);
+    const float f1 = __expf(m - M), f2 = __expf(m2 - M);
+    l = l * f1 + q[ccat_p] * f2;
+    s1 = s1 * f1 + q[2 * ccat_p] * f2;
+    s2 = s2 * f1 + q[3 * ccat_p] * f2;
+    m = M;
+  }
+  const float mean = s1 / l;
+  const float var = s2 / l - mean * mean;
+  pooled[(size_t)b * 2 * ccat_p + co] = mean;
+  pooled[(size_t)b * 2 * ccat_p + ccat_p + co] = sqrtf(fmaxf(var, 1e-9f));
+}
+
 template <typename T>
 int launch_t(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh, const int32_t* d_row_off, int B,
-             float* d_pooled, hipStream_t s) {
+             int t_max, float* d_pooled, float* d_part, hipStream_t s) {
   const int smem = 2 * PT * (BOTT + PC) * (int)sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
     SUGAR_HIP(hipFuncSetAttribute((const void*)pool_stats_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  const dim3 grid((unsigned)ceil_div(P.ccat_p, PC), (unsigned)B);
+  const dim3 grid((unsigned)ceil_div(P.ccat_p, PC), (unsigned)B, (unsigned)ceil_div(t_max, POOL_SEG));
   hipLaunchKernelGGL(pool_stats_kernel<T>, grid, dim3(512), smem, s, (const T*)d_a, lda, (const T*)d_h, ldh,
-                     (const T*)P.w2, P.ccat_p, d_row_off, d_pooled);
+                     (const T*)P.w2, P.ccat_p, d_row_off, d_pooled, d_part);
   SUGAR_LAUNCH_CHECK();
+  if (t_max > POOL_SEG) {
+    hipLaunchKernelGGL(pool_merge_kernel, dim3((unsigned)ceil_div(P.ccat_p, 256), (unsigned)B), dim3(256), 0, s, d_part,
+                       P.ccat_p, d_row_off, d_pooled);
+    SUGAR_LAUNCH_CHECK();
+  }
   return SUGAR_OK;
 }
 
 }  // namespace
 
+int64_t pool_part_floats(const PoolLayer& P, int B, int64_t R) { return (R / POOL_SEG + B + 1) * 4 * (int64_t)P.ccat_p; }
+
 int launch_pool_stats(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh,
-                      const int32_t* d_row_off, int B, float* d_pooled, int dtype, hipStream_t s) {
+                      const int32_t* d_row_off, int B, int t_max, float* d_pooled, float* d_part, int dtype,
+                      hipStream_t s) {
+  SUGAR_CHECK_ARG(t_max > 0 && (t_max <= POOL_SEG || d_part), "pool: segment table missing (t_max %d)", t_max);
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(P.bott == BOTT, "pool: bottleneck %d unsupported (reference fixes 128, dynamictdnn.py:494)", P.bott);
   SUGAR_CHECK_ARG(lda % E == 0 && ldh % E == 0 && P.ccat_p % E == 0 && ((uintptr_t)d_a & 15) == 0 &&
                       ((uintptr_t)d_h & 15) == 0,
                   "pool: unaligned activations");
-  if (dtype == SUGAR_F32) return launch_t<float>(P, d_a, lda, d_h, ldh, d_row_off, B, d_pooled, s);
-  return launch_t<bf16>(P, d_a, lda, d_h, ldh, d_row_off, B, d_pooled, s);
+  if (dtype == SUGAR_F32) return launch_t<float>(P, d_a, lda, d_h, ldh, d_row_off, B, t_max, d_pooled, d_part, s);
+  return launch_t<bf16>(P, d_a, lda, d_h, ldh, d_row_off, B, t_max, d_pooled, d_part, s);
 }
 
 }  // namespace sugar

@@ -285,7 +285,7 @@ struct Workspace {
   int2* rowseg;
   float* logmel;
   void *feats, *featp, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
-  float *semean, *sescale, *pooled, *tailpart;
+  float *semean, *sescale, *pooled, *poolpart, *tailpart;
   double* bnpart;    // recalibration: partial sums, batch (scale, shift), pre-BN embeddings
   float *bnscale, *bnshift, *embpre;
   int64_t bytes;
@@ -301,7 +301,7 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   };
   Workspace w;
   w.rowseg = (int2*)take(R * (int64_t)sizeof(int2));
-  w.logmel = (float*)take(R * SUGAR_N_MELS * 4);
+  w.logmel = (float*)take(fbank_scratch_floats(B, R) * 4);
   w.feats = take(R * SUGAR_N_MELS * esz);
   w.featp = take(gemm_taps_pad_rows(n->layer1, B, R) * n->in_feats * esz);   // zero-padded copy for the layer1 GEMM
   w.S = take(R * n->c0p * esz);
@@ -314,6 +314,7 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   w.semean = (float*)take((int64_t)B * n->c0p * 4);
   w.sescale = (float*)take((int64_t)B * n->c0p * 4);
   w.pooled = (float*)take((int64_t)B * 2 * n->ccatp * 4);
+  w.poolpart = (float*)take(pool_part_floats(n->pool, B, R) * 4);
   w.tailpart = (float*)take((int64_t)tail_splits(n->tail) * B * n->embed * 4);
   const int cbn = n->c0p > n->midp_max ? n->c0p : n->midp_max;
   w.bnpart = (double*)take((int64_t)bn_workspace_doubles(cbn) * 8);
@@ -397,7 +398,7 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
   p1.x = w.hbuf; p1.ldx = n->ccatp; p1.y = w.abuf; p1.ldy = n->bott;
   { Prof p(SUGAR_STAGE_POOL1, s); if ((rc = launch_conv(n->pool1, p1, w.rowseg, R, dt, s))) return rc; }
   if ((rc = tapcopy(102, w.abuf, n->bott, n->bott))) return rc;
-  { Prof p(SUGAR_STAGE_POOL_STATS, s); if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, w.pooled, dt, s))) return rc; }
+  { Prof p(SUGAR_STAGE_POOL_STATS, s); if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, t_max, w.pooled, w.poolpart, dt, s))) return rc; }
   if (tap == 101 && tap_out)
     SUGAR_HIP(hipMemcpyAsync(tap_out, w.pooled, (size_t)B * 2 * n->ccatp * 4, hipMemcpyDeviceToDevice, s));
   Prof p(SUGAR_STAGE_TAIL, s);
@@ -472,7 +473,7 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
   ConvIO p1;
   p1.x = w.hbuf; p1.ldx = n->ccatp; p1.y = w.abuf; p1.ldy = n->bott;
   if ((rc = launch_conv(n->pool1, p1, w.rowseg, R, dt, s))) return rc;
-  if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, w.pooled, dt, s))) return rc;
+  if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, t_max, w.pooled, w.poolpart, dt, s))) return rc;
   // unfolded tail: bnpool (statistics over the B utterances) -> linear -> bnembed        dynamictdnn.py:664-665
   if ((rc = launch_bn_rows(w.pooled, 2 * n->ccatp, B, n->bn_pool, momentum, s))) return rc;
   if ((rc = launch_tail(n->tail_raw, w.pooled, B, w.tailpart, w.embpre, 0, s))) return rc;
@@ -569,10 +570,18 @@ int64_t sugar_workspace_bytes(const SugarSubnet* net, int B, int64_t R) {
   return plan(net, B, R, nullptr).bytes;
 }
 
+int64_t sugar_fbank_scratch_bytes(int B, int64_t R) {
+  if (B <= 0 || R <= 0) {
+    set_error("fbank_scratch_bytes: bad arguments");
+    return SUGAR_EINVAL;
+  }
+  return fbank_scratch_floats(B, R) * 4;
+}
+
 int sugar_fbank_fwd(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
-                    const int32_t* d_row_off, int B, int t_max, float* d_logmel, void* d_feats, int dtype,
+                    const int32_t* d_row_off, int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype,
                     void* stream) {
-  return launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, d_logmel, d_feats, dtype, (hipStream_t)stream);
+  return launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, d_logmel, d_feats, dtype, (hipStream_t)stream);
 }
 
 int sugar_tdnn_fwd(const SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R, int t_max,
@@ -591,7 +600,7 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
   SUGAR_CHECK_ARG(d_wav_off && d_wav_len, "embed_fwd: null pointer");
   const Workspace w = plan(net, B, R, d_workspace);
   hipStream_t s = (hipStream_t)stream;
-  { Prof p(SUGAR_STAGE_FBANK, s); if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, w.logmel, w.feats, net->dtype, s))) return rc; }
+  { Prof p(SUGAR_STAGE_FBANK, s); if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, w.logmel, w.feats, net->dtype, s))) return rc; }
   return tdnn_forward(net, w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
 }
 
@@ -617,7 +626,7 @@ int sugar_embed_recalibrate(SugarSubnet* net, const float* d_wav, const int64_t*
   SUGAR_CHECK_ARG(B > 1, "recalibrate: train-mode BatchNorm needs more than one utterance per batch");
   const Workspace w = plan(net, B, R, d_workspace);
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, t_max, w.logmel, w.feats, net->dtype, s))) return rc;
+  if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, w.logmel, w.feats, net->dtype, s))) return rc;
   return tdnn_recalibrate(net, w.feats, d_row_off, B, R, t_max, w, momentum, d_emb, s);
 }
 

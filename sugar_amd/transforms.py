@@ -79,10 +79,13 @@ class LogMelFbanks(nn.Module):
         if not wav_flat.is_cuda:
             raise _lib.SugarError("sugar_amd runs on an MI355X only: waveforms must be CUDA tensors (no CPU fallback)")
         dev = wav_flat.device
-        logmel = torch.empty(plan.R, self.n_mels, dtype=torch.float32, device=dev)
+        nbytes = _lib.lib().sugar_fbank_scratch_bytes(plan.B, plan.R)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "sugar_fbank_scratch_bytes")
+        logmel = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         feats = torch.empty(plan.R, self.n_mels, dtype=dtype, device=dev)
         rc = _lib.lib().sugar_fbank_fwd(wav_flat.data_ptr(), plan.wav_off.data_ptr(), plan.wav_len.data_ptr(),
-                                        plan.row_off.data_ptr(), plan.B, plan.t_max, logmel.data_ptr(),
+                                        plan.row_off.data_ptr(), plan.B, plan.R, plan.t_max, logmel.data_ptr(),
                                         feats.data_ptr(), _lib.SUGAR_F32 if dtype == torch.float32 else _lib.SUGAR_BF16,
                                         torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "sugar_fbank_fwd")

@@ -82,6 +82,30 @@ def test_variable_length_equals_reference_one_at_a_time(precision, golden, meta,
     assert (emb_p - emb[perm]).abs().max() < (1e-4 if precision == "fp32" else 1e-2)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["base", "largest"])
+def test_long_utterances_time_segments(name, precision, supernet):
+    """Whole-utterance evaluation (the reference's num_samples=0 mode, sugar/waveforms.py:105-113) of 6.9 / 11 / 21 /
+    1 s audio against the reference's own embeddings (tests/golden/long.npz): these lengths run the time-segmented
+    Res2 chain (> 384 frames), the chunked instance norm (> 320) and the segmented attentive pooling (> 1024)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "long.npz"))
+    cfg = layout.BASE if name == "base" else layout.LARGEST
+    model = _model(supernet, cfg, precision)
+    wavs = [w.to(DEV) for w in synth.ragged_waveforms([int(n) for n in g["lengths"]], seed=int(g["seed"]))]
+    emb = model(wavs)
+    want = g["embed/%s/long" % name]
+    c, r = _cos(emb, want), _relerr(emb, want)
+    print("long", name, precision, c.tolist(), "rel L2 err max %.2e" % r)
+    assert c.min() >= TOL[precision]
+    assert r < REL[precision]
+    # an utterance's embedding does not depend on what else is in the batch (fixed segment lengths)
+    solo = torch.cat([model([w]) for w in wavs])
+    assert (solo - emb).abs().max() < (1e-4 if precision == "fp32" else 1e-2)
+    if precision == "bf16":
+        assert torch.equal(model([wavs[2], wavs[3]])[0], model([wavs[2]])[0])
+
+
 def test_supernet_with_active_config_equals_clone(golden, meta, supernet):
     """Reference property: sup.config = cfg; sup(x) == sup.clone(cfg)(x)."""
     cfg = cfg_of(meta, "rand0")

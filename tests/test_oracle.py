@@ -78,6 +78,18 @@ def test_ragged_one_at_a_time(golden, meta, sup_state):
     assert _rel(e.numpy(), golden["embed/base/ragged"]) < 2e-5
 
 
+def test_long_utterances_match_reference(sup_state):
+    """Whole-utterance evaluation of 7-21 s audio (tests/golden/long.npz, made by oracle/make_golden_long.py from the
+    reference's own cloned subnets): the lengths at which the GPU path cuts utterances into time segments."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "long.npz"))
+    wavs = synth.ragged_waveforms([int(n) for n in g["lengths"]], seed=int(g["seed"]))
+    osd = ref_cpu.clone_state(sup_state, layout.BASE)
+    got = ref_cpu.embed_ragged(osd, layout.BASE[0], wavs)
+    want = torch.from_numpy(g["embed/base/long"])
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-5
+
+
 def test_bn_file_override(golden, meta, sup_state):
     sd = ref_cpu.clone_state(sup_state, layout.BASE)
     shapes = layout.subnet_shapes(layout.BASE)
