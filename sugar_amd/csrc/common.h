@@ -45,6 +45,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  Function attributes are per device, so the "done" state is a
+// bit per device ordinal (one word per call site); a race between two threads only repeats the call.
+static inline int lds_opt_in(const void* fn, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  SUGAR_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && ((*done_mask >> dev) & 1ull)) return SUGAR_OK;
+  SUGAR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (dev >= 0 && dev < 64) *done_mask |= 1ull << dev;
+  return SUGAR_OK;
+}
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
@@ -147,8 +158,9 @@ struct SELayer {            // device, f32, transposed for coalesced reads
   int c = 0, c_p = 0, hid = 0;
 };
 // scale[b][c] = sigmoid(W2 relu(W1 mean_t(y[b]) + b1) + b2)
-int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, float* d_mean,
-                    float* d_scale, int dtype, hipStream_t s);
+int64_t se_part_floats(int c_p, int B, int64_t R);   // d_part: segment sums of utterances longer than 2048 frames
+int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, int t_max,
+                    float* d_mean, float* d_part, float* d_scale, int dtype, hipStream_t s);
 // out = y * scale[b] + S ;  S += out (skipped when d_S_out == nullptr)
 int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, void* d_S, int ldS, void* d_out,
                     int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s);

@@ -342,11 +342,8 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, in
 template <int TM, int TN, int NS, int PP = 0>
 int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = NS * (TM + TN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SUGAR_HIP(hipFuncSetAttribute((const void*)gemm1x1_kernel<TM, TN, NS, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  static unsigned long long opted = 0;
+  if (int rc = lds_opt_in((const void*)gemm1x1_kernel<TM, TN, NS, PP>, smem, &opted)) return rc;
   const int grid = a.n_co_tiles * (int)ceil_div(a.R, TN);
   hipLaunchKernelGGL((gemm1x1_kernel<TM, TN, NS, PP>), dim3(grid), dim3(512), smem, s, a);
   SUGAR_LAUNCH_CHECK();
@@ -356,12 +353,13 @@ int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
 template <int PP = 0>
 int launch_split(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = 2 * (256 + 256) * 128;
-  static int n_cu = 0;
+  static unsigned long long opted = 0;
+  if (int rc = lds_opt_in((const void*)gemm1x1_split_kernel<2, PP>, smem, &opted)) return rc;
+  static int n_cu = 0;                       // every GPU of a node is the same part
   if (!n_cu) {
     int dev = 0;
     SUGAR_HIP(hipGetDevice(&dev));
     SUGAR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    SUGAR_HIP(hipFuncSetAttribute((const void*)gemm1x1_split_kernel<2, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   }
   const int total = a.n_co_tiles * (int)ceil_div(a.R, 256);
   const int n_main = total / n_cu * n_cu, tail = total - n_main;

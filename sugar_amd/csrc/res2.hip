@@ -362,12 +362,8 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   const bool w3 = a.k_pad <= 192;
 #define R2_CASE(M, TP, WR)                                                                                     \
   {                                                                                                            \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      SUGAR_HIP(hipFuncSetAttribute((const void*)res2_chain_kernel<M, TP, WR>,                                 \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
+    static unsigned long long opted = 0;                                                                       \
+    if (int rc = lds_opt_in((const void*)res2_chain_kernel<M, TP, WR>, 160 * 1024, &opted)) return rc;         \
     hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR>), dim3(B, nseg_max), dim3(512), smem, s, a);                        \
   }
 #define R2_CASE_W(M, TP) \

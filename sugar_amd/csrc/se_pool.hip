@@ -45,15 +45,24 @@ struct Chunk<bf16> {
 };
 
 // ------------------------------------------------------------------------------------------ SE scale
-// se_mean_kernel: grid (channel slabs of 8 chunks, utterances); 256 threads = 8 chunks x 32 row lanes.
+// se_mean_kernel: grid (channel slabs of 8 chunks, utterances, time segments); 256 threads = 8 chunks x 32 row lanes.
+// Utterances longer than SE_SEG frames are summed in segments of SE_SEG frames (fixed: the result does not depend on
+// the rest of the batch); the segment sums go to a table that se_mlp_kernel adds up in order.
+constexpr int SE_SEG = 2048;
+
+__device__ __forceinline__ int se_slot(const int32_t* row_off, int b) { return row_off[b] / SE_SEG + b; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, int ldy, int c_p,
                                                       const int32_t* __restrict__ row_off,
-                                                      float* __restrict__ mean) {
+                                                      float* __restrict__ mean, float* __restrict__ part) {
   constexpr int E = Chunk<T>::N;
   __shared__ float partial[32][8 * E + 1];
   const int b = blockIdx.y, tid = threadIdx.x;
-  const int s = row_off[b], n = row_off[b + 1] - s;
+  const int s_utt = row_off[b], n_utt = row_off[b + 1] - s_utt;
+  const int seg0 = blockIdx.z * SE_SEG;
+  if (seg0 >= n_utt) return;
+  const int s = s_utt + seg0, n = min(SE_SEG, n_utt - seg0);
   const int tx = tid & 7, ty = tid >> 3;
   const int c0 = (blockIdx.x * 8 + tx) * E;
   float acc[E];
@@ -78,21 +87,34 @@ __global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, i
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < 32; ++k) t += partial[k][tid];
-      mean[(size_t)b * c_p + c] = t / (float)n;
+      if (n_utt > SE_SEG) part[(size_t)(se_slot(row_off, b) + blockIdx.z) * c_p + c] = t;
+      else mean[(size_t)b * c_p + c] = t / (float)n;
     }
   }
 }
 
 // se_mlp_kernel: one 1024-thread workgroup per utterance; both tiny GEMVs split over k so no thread walks more
 // than ~64 weights, weights stored transposed so every load is coalesced.
-__global__ __launch_bounds__(1024) void se_mlp_kernel(const float* __restrict__ mean, SELayer se,
+__global__ __launch_bounds__(1024) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ segsum,
+                                                      const int32_t* __restrict__ row_off, SELayer se,
                                                       float* __restrict__ scale) {
   extern __shared__ float sm[];          // mean [c_p] | hidden [hid] | partial [1024]
   float* m = sm;
   float* hidden = sm + se.c_p;
   float* part = hidden + se.hid;
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < se.c_p; c += 1024) m[c] = mean[(size_t)b * se.c_p + c];
+  const int n_utt = row_off[b + 1] - row_off[b];
+  if (n_utt > SE_SEG) {                              // long utterance: add up its segment sums
+    const int nseg = (n_utt + SE_SEG - 1) / SE_SEG;
+    const float* p = segsum + (size_t)se_slot(row_off, b) * se.c_p;
+    for (int c = tid; c < se.c_p; c += 1024) {
+      float t = 0.f;
+      for (int k = 0; k < nseg; ++k) t += p[(size_t)k * se.c_p + c];
+      m[c] = t / (float)n_utt;
+    }
+  } else {
+    for (int c = tid; c < se.c_p; c += 1024) m[c] = mean[(size_t)b * se.c_p + c];
+  }
   __syncthreads();
   {  // hidden = relu(W1 mean + b1): thread (j, kp), kp-th slice of the channel range
     const int KP = 1024 / se.hid > 0 ? 1024 / se.hid : 1;
@@ -244,19 +266,24 @@ __global__ __launch_bounds__(64) void l2norm_kernel(float* __restrict__ x, int d
 
 }  // namespace
 
-int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, float* d_mean,
-                    float* d_scale, int dtype, hipStream_t s) {
+int64_t se_part_floats(int c_p, int B, int64_t R) { return (R / SE_SEG + B + 1) * (int64_t)c_p; }
+
+int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, int t_max,
+                    float* d_mean, float* d_part, float* d_scale, int dtype, hipStream_t s) {
+  SUGAR_CHECK_ARG(t_max > 0 && (t_max <= SE_SEG || d_part), "se: segment table missing (t_max %d)", t_max);
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(se.c_p % E == 0 && se.c_p > 0, "se: channels %d unsupported", se.c_p);
   SUGAR_CHECK_ARG(se.hid > 0 && se.hid <= 1024 && ldy % E == 0, "se: bad hidden %d / ld %d", se.hid, ldy);
-  const dim3 grid((unsigned)ceil_div(se.c_p / E, 8), (unsigned)B);
+  const dim3 grid((unsigned)ceil_div(se.c_p / E, 8), (unsigned)B, (unsigned)ceil_div(t_max, SE_SEG));
   if (dtype == SUGAR_F32)
-    hipLaunchKernelGGL(se_mean_kernel<float>, grid, dim3(256), 0, s, (const float*)d_y, ldy, se.c_p, d_row_off, d_mean);
+    hipLaunchKernelGGL(se_mean_kernel<float>, grid, dim3(256), 0, s, (const float*)d_y, ldy, se.c_p, d_row_off, d_mean,
+                       d_part);
   else
-    hipLaunchKernelGGL(se_mean_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_y, ldy, se.c_p, d_row_off, d_mean);
+    hipLaunchKernelGGL(se_mean_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_y, ldy, se.c_p, d_row_off, d_mean,
+                       d_part);
   SUGAR_LAUNCH_CHECK();
   const size_t smem = (se.c_p + se.hid + 1024) * sizeof(float);
-  hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(1024), smem, s, d_mean, se, d_scale);
+  hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(1024), smem, s, d_mean, d_part, d_row_off, se, d_scale);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }

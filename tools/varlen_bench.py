@@ -27,6 +27,10 @@ cases = {
     "2-20 s x 96": list(rng.integers(32000, 320000, 96)),
     "6.5-20 s x 64": list(rng.integers(104000, 320000, 64)),
     "60 s x 16": [960000] * 16,
+    "3 s x 1": [48000],
+    "8 s x 1": [128000],
+    "3 s x 8": [48000] * 8,
+    "145 s x 1": [2320000],
 }
 for name, lens in cases.items():
     wavs = [torch.randn(int(n), device=dev) for n in lens]
