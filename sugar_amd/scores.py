@@ -52,23 +52,43 @@ def score_trials(trials, vectors, mode="cosine", n_jobs=4):
     """
     if mode != "cosine":
         raise ValueError("only mode='cosine' is on the accelerated path (got %r)" % (mode,))
-    keys = list(vectors.keys())
+    matrix = getattr(vectors, "matrix", None)
+    if matrix is not None:                       # a VectorTable from extract_vectors: one matrix, offsets on the device
+        keys, vec, seg_off, dev = vectors.files, matrix, vectors.seg_off, matrix.device
+    else:
+        keys = list(vectors.keys())
+        dev = vectors[keys[0]].device
+        seg = [0]
+        for k in keys:
+            seg.append(seg[-1] + vectors[k].shape[0])
+        vec = torch.cat([vectors[k].reshape(-1, vectors[k].shape[-1]) for k in keys], dim=0)
+        seg_off = torch.tensor(seg, dtype=torch.int32, device=dev)
+    labels, pairs, e_dev, t_dev = _trial_index(trials, keys, dev)
+    scores = score_pairs(vec, seg_off, e_dev, t_dev)
+    return scores.double().cpu().numpy(), labels, pairs
+
+
+def _trial_index(trials, keys, dev):
+    """(labels ndarray, [[enroll, test], ...], enroll row index, test row index on `dev`) of a trial list against the
+    utterance order `keys`.  A sweep scores the same list once per subnet, so the result is remembered on the trial
+    object when it accepts attributes (VerificationTrials does; a plain list does not)."""
+    memo = getattr(trials, "_sugar_trial_index", None)
+    if memo is not None and memo[0] is keys and memo[1] == len(trials) and memo[2] == dev:
+        return memo[3]
     index = {k: i for i, k in enumerate(keys)}
-    dev = vectors[keys[0]].device
-    seg = [0]
-    for k in keys:
-        seg.append(seg[-1] + vectors[k].shape[0])
-    vec = torch.cat([vectors[k].reshape(-1, vectors[k].shape[-1]) for k in keys], dim=0)
     labels, pairs, e_idx, t_idx = [], [], [], []
     for tr in trials:
         labels.append(tr["label"])
         pairs.append([tr["enroll"], tr["test"]])
         e_idx.append(index[tr["enroll"]])
         t_idx.append(index[tr["test"]])
-    scores = score_pairs(vec, torch.tensor(seg, dtype=torch.int32, device=dev),
-                         torch.tensor(e_idx, dtype=torch.int32, device=dev),
-                         torch.tensor(t_idx, dtype=torch.int32, device=dev))
-    return scores.double().cpu().numpy(), np.array(labels), pairs
+    out = (np.array(labels), pairs, torch.from_numpy(np.asarray(e_idx, dtype=np.int32)).to(dev),
+           torch.from_numpy(np.asarray(t_idx, dtype=np.int32)).to(dev))
+    try:
+        trials._sugar_trial_index = (keys, len(trials), dev, out)     # `keys is` the packed list's file list
+    except AttributeError:
+        pass
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ score normalisation

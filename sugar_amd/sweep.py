@@ -1,0 +1,127 @@
+"""
+NAS subnet-evaluation sweep (BASELINE config 5; the loop of tutorials/EfficientTDNN/SubnetEvaluation.ipynb cell
+`ec189126` and TDNN-NAS.ipynb cell 24):
+
+    for config in configs:
+        subnet = supernet.clone(config)              # sugar/models/dynamictdnn.py:713-730
+        batch_forward(train_loader, model)           # BN recalibration, sugar/models/__init__.py:201-242
+        eer, dcf = veri_validate(veri_loader, model) # sugar/models/__init__.py:535-595
+
+The reference runs the configs one after another on one GPU.  Here the configs are dealt to the ranks (one process per
+GPU, longest first by multiply-adds, no collective on the data path: every rank embeds the whole evaluation list with
+its own subnets), and on each rank the NEXT subnet is cloned and packed for the GPU on a host thread while the
+current one is being evaluated (clone + pack is 8-12 ms of host work against 12-30 ms of GPU work for 4 874
+utterances, tools/clone_bench.py).  The evaluation list is staged on the GPU once (PackedUtterances) and the trial
+index arrays are built once, so a subnet costs its GPU time and little else.  The only exchange is one
+all_gather_object of the per-config results.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+from . import _lib
+from .dynamictdnn import DynamicTDNN, TDNNSubnet
+from .models import SpeakerModel, WrappedModel, batch_forward, veri_validate
+from .transforms import LogMelFbanks
+from .vectors import PackedUtterances, extract_vectors, shard_indices
+
+
+def config_key(config):
+    """Hashable form of a subnet config (depth, channels, kernels, catconv)."""
+    depth, ch, ks, ccat = config
+    return (int(depth), tuple(int(c) for c in ch), tuple(int(k) for k in ks), int(ccat))
+
+
+def _cost(supernet, config, frames=300):
+    """Multiply-adds of `config` by the reference's own count (dynamictdnn.py:735-765); restores the active config."""
+    saved = supernet.config
+    try:
+        supernet.config = config
+        return supernet.count_ops((1, supernet.in_feats, frames))
+    finally:
+        supernet.config = saved
+
+
+def _prepare(supernet, config, precision, dev):
+    """clone(config) without touching the supernet's active config (safe on a host thread), packed for `dev`."""
+    cfg, state = supernet.materialize(config)
+    sub = TDNNSubnet(cfg, state, supernet.in_feats, supernet.out_embeds, precision)
+    sub.to(dev)
+    sub.handle(dev)                                    # sugar_subnet_create: fold BN, pack, upload
+    return sub
+
+
+def shard_configs(supernet, configs, rank, world):
+    """Indices of `configs` this rank evaluates: longest-first round-robin by multiply-adds (same rule as utterances)."""
+    return shard_indices(len(configs), rank, world, weights=[_cost(supernet, c) for c in configs])
+
+
+def gather_results(local, world=None):
+    """{config_key: result} of this rank -> the union over all ranks (one all_gather_object; identity without a
+    process group)."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()):
+        return dict(local)
+    world = dist.get_world_size() if world is None else world
+    if world <= 1:
+        return dict(local)
+    parts = [None] * world
+    dist.all_gather_object(parts, local)
+    out = {}
+    for p in parts:
+        out.update(p)
+    return out
+
+
+def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transform=None, device="cuda:0",
+                     precision="bf16", norm=True, p_target=0.05, prefetch=True, rank=None, world=None, gather=True,
+                     on_result=None):
+    """
+    Evaluate every subnet config of `configs` (an iterable of (depth, channels, kernels, catconv)) cloned from
+    `supernet` (a DynamicTDNN holding the supernet weights): optional BN recalibration over `recal_loader`
+    (batch_forward), then veri_validate over `veri_loader`.
+
+    Returns {config_key: {"eer": .., "eer_thresh": .., "mindcf": .., "mindcf_thresh": .., "rank": ..}} for ALL configs
+    on every rank when `gather` (one all_gather_object), else for this rank's share.  `rank` / `world` default to
+    torch.distributed's when it is initialised, else 0 / 1.  `on_result(config, result)` is called as results arrive.
+    """
+    if not isinstance(supernet, DynamicTDNN):
+        raise TypeError("evaluate_subnets expects the DynamicTDNN supernet, got %s" % type(supernet).__name__)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.SugarError("sugar_amd runs on an MI355X only: pass device='cuda:N' (there is no CPU fallback)")
+    dist = torch.distributed
+    live = dist.is_available() and dist.is_initialized()
+    if rank is None:
+        rank = dist.get_rank() if live else 0
+    if world is None:
+        world = dist.get_world_size() if live else 1
+    configs = [config_key(c) for c in configs]
+    mine = [configs[i] for i in shard_configs(supernet, configs, rank, world)]
+    fb = transform if transform is not None else LogMelFbanks()
+    # the evaluation list is walked and staged on the GPU once for all subnets
+    packed = PackedUtterances(veri_loader.dataset.utterances, dev, batch_size=max(1, int(veri_loader.batch_size)))
+    results = {}
+    pool = ThreadPoolExecutor(max_workers=1) if prefetch and len(mine) > 1 else None
+    try:
+        nxt = pool.submit(_prepare, supernet, mine[0], precision, dev) if pool and mine else None
+        for i, cfg in enumerate(mine):
+            sub = nxt.result() if nxt is not None else _prepare(supernet, cfg, precision, dev)
+            nxt = pool.submit(_prepare, supernet, mine[i + 1], precision, dev) if pool and i + 1 < len(mine) else None
+            model = WrappedModel(SpeakerModel(sub, transform=fb)).to(dev).eval()
+            if recal_loader is not None:
+                batch_forward(recal_loader, model, device=str(dev))
+            with torch.no_grad():
+                vectors = extract_vectors(model, packed, norm=norm)
+                eer, dcf = veri_validate(veri_loader, model, norm=norm, p_target=p_target, device=str(dev),
+                                         vectors=vectors)
+            res = {"eer": float(eer[0]), "eer_thresh": float(eer[1]), "mindcf": float(dcf[0]),
+                   "mindcf_thresh": float(dcf[1]), "rank": rank}
+            results[cfg] = res
+            if on_result is not None:
+                on_result(cfg, res)
+            sub.release()                              # device weights of a finished subnet
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
+    return gather_results(results, world) if gather else results

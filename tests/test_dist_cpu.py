@@ -54,3 +54,40 @@ def test_allgather_uneven_shards_world2():
 def test_gather_without_process_group_is_identity():
     x = torch.ones(3, 192)
     assert gather_vectors(x)[0] is x
+
+
+# ---- NAS sweep (BASELINE config 5): configs dealt to ranks by multiply-adds, results gathered once ------------------
+def _sweep_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sugar_amd
+    from sugar_amd.sweep import config_key, gather_results, shard_configs
+    sup = sugar_amd.tdnn8m2g()
+    path = sugar_amd.TDNNPath(sup.space(mode=["kernel", "depth", "width1", "width2"]))
+    configs = [config_key(path.sample()) for _ in range(11)]
+    before = sup.config
+    mine = shard_configs(sup, configs, rank, world)
+    assert sup.config == before                      # costing the configs leaves the active config alone
+    # stand-in for the evaluation this rank ran on its GPU
+    local = {configs[i]: {"eer": float(i), "rank": rank} for i in mine}
+    full = gather_results(local)
+    q.put((rank, mine, sorted(full.items())))
+    dist.destroy_process_group()
+
+
+def test_sweep_shards_and_gathers_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, mine0, full0), (r1, mine1, full1) = res
+    assert sorted(mine0 + mine1) == list(range(11)) and abs(len(mine0) - len(mine1)) <= 1
+    assert full0 == full1 and len(full0) == len({k for k, _ in full0})
+    for _, v in full0:
+        assert int(v["eer"]) in (mine0 if v["rank"] == 0 else mine1)

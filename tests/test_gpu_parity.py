@@ -218,6 +218,38 @@ def test_veri_validate_matches_oracle_pipeline(supernet):
     assert eer2 == eer and dcf2 == dcf
 
 
+def test_subnet_sweep_equals_one_at_a_time(meta, supernet):
+    """BASELINE config 5 on one rank: evaluate_subnets (next subnet cloned and packed on a host thread while the current
+    one runs) gives exactly the numbers of clone -> [batch_forward] -> veri_validate per config, and leaves the
+    supernet's active config alone."""
+    n_utts = 12
+    lens = synth.ragged_lengths(n_utts, lo=24000, hi=40000, seed=13).tolist()
+    wavs = synth.ragged_waveforms(lens, seed=13)
+    lab, a, b = synth.trial_pairs(n_utts, 120, seed=13)
+    trials = _Trials({"label": int(lab[i]), "enroll": "utt%04d.wav" % a[i], "test": "utt%04d.wav" % b[i]}
+                     for i in range(len(lab)))
+    trials.utterances = _Utts(wavs, [1] * n_utts)
+    loader = _Loader(trials, 4)
+    recal = [(synth.waveforms(6, 32000, seed=40 + i),) for i in range(2)]
+    configs = [cfg_of(meta, n) for n in ("smallest", "rand0", "odd", "rand1")]
+    supernet.config = None
+    before = supernet.config
+    for recal_loader in (None, recal):
+        seen = []
+        got = sugar_amd.evaluate_subnets(supernet, configs, loader, recal_loader=recal_loader, device=DEV,
+                                         on_result=lambda c, r: seen.append(c))
+        assert supernet.config == before
+        assert len(got) == len(configs) and sorted(seen) == sorted(got)
+        for cfg in configs:
+            model = _model(supernet, cfg, "bf16")
+            supernet.config = None
+            if recal_loader is not None:
+                sugar_amd.batch_forward(recal_loader, model, device=DEV)
+            eer, dcf = sugar_amd.veri_validate(loader, model, device=DEV)
+            key = (cfg[0], tuple(cfg[1]), tuple(cfg[2]), cfg[3])
+            assert got[key]["eer"] == eer[0] and got[key]["mindcf"] == dcf[0], (cfg, got[key], eer, dcf)
+
+
 def test_full_size_batch256_properties(supernet):
     """BASELINE config 2 size (256 x 3 s, Base, bf16): size-independent properties instead of a CPU oracle run."""
     model = _model(supernet, layout.BASE, "bf16")
