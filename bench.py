@@ -68,6 +68,9 @@ def main():
                          "the per-kernel roofline clean; the 2-stream rate (consecutive batches overlapping on the GPU) "
                          "is measured after the timed region and reported as 'pipelined'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the 2-stream leg after the timed region (rocprofv3 runs: its overlapped kernels would "
+                         "be averaged into the per-kernel durations)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage hipEvent breakdown to stderr")
     args = ap.parse_args()
 
@@ -148,7 +151,7 @@ def main():
     # after the timed region: the same K steps alternating over two streams (HBM-bound kernels of one batch under
     # the MFMA-bound kernels of the next); reported beside `value`, never as `value`
     pipelined = None
-    if len(lanes) == 1:
+    if len(lanes) == 1 and not args.no_pipelined:
         lanes2 = [torch.cuda.Stream(dev) for _ in range(2)]
 
         def step2(i):
