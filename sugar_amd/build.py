@@ -16,6 +16,15 @@ HEADERS = ["common.h", os.path.join("..", "..", "include", "sugar_amd.h")]
 LIB = os.path.join(HERE, "libsugar_amd.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=on"]
+# Packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) are switched off for the whole library:
+# on MI355X a wave's packed-FP32 results were occasionally wrong while ANOTHER wave on the same CU issued MFMAs
+# (tools/fbank_corun.hip: the front-end kernel against a pure-MFMA burner on a second stream, 62 560 disagreeing
+# spectrum bins in 600 launches; 0 with the feature off; 0 against VALU / LDS / memory burners).  Two HIP streams
+# (extract_vectors, bench.py's pipelined leg) put exactly that mix on a CU.  DESIGN.md section 5b.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA_FLAGS = {}
+if os.environ.get("SUGAR_ALLOW_PACKED_FP32") is None:
+    FLAGS += NO_PACKED_FP32
 
 
 def _stale():
@@ -36,11 +45,13 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
+        # the host pass of hipcc does not know the device feature and says so once per file
+        out = "\n".join(l for l in out.splitlines() if "packed-fp32-ops' is not a recognized feature" not in l)
         if verbose and out.strip():
             print("[hipcc %s]\n%s" % (src, out))
         failed |= p.returncode != 0

@@ -69,17 +69,35 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, 
   }
 }
 
+// 256 threads = 32 channels x 8 partial lanes: every lane adds its partials (k = lane, lane + 8, ...: independent
+// loads), the 8 lane sums of a channel are added in lane order, so the result does not depend on scheduling.  (One
+// thread per channel walking all 128 partials was a 36 us chain of dependent loads, 28 times per step.)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblk, int C, double n,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, float momentum,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nblk; ++k) {
-    a += part[((size_t)k * 2 + 0) * C + c];
-    b += part[((size_t)k * 2 + 1) * C + c];
+  if (c < C) {
+#pragma unroll 4
+    for (int k = ty; k < nblk; k += 8) {
+      a += part[((size_t)k * 2 + 0) * C + c];
+      b += part[((size_t)k * 2 + 1) * C + c];
+    }
+  }
+  red[0][ty][tx] = a;
+  red[1][ty][tx] = b;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  a = 0.0;
+  b = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a += red[0][k][tx];
+    b += red[1][k][tx];
   }
   const double mean = a / n;
   double var = b / n - mean * mean;
@@ -110,24 +128,43 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(T* __restrict__ z, int ld
   }
 }
 
-// x [B][ld] f32, one thread per channel: train-mode BN in place + running update (bnpool, bnembed)
+// x [B][ld] f32: train-mode BN in place + running update (bnpool, bnembed).  256 threads = 32 channels x 8 row lanes;
+// lane sums are added in lane order (deterministic).
 __global__ __launch_bounds__(256) void bn_rows_kernel(float* __restrict__ x, int ld, int B, int C,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ rmean, float* __restrict__ rvar,
                                                       float momentum) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  const bool ok = c < C;
   double a = 0.0, b = 0.0;
-  for (int r = 0; r < B; ++r) {
-    const double v = x[(size_t)r * ld + c];
-    a += v;
-    b += v * v;
+  if (ok) {
+#pragma unroll 4
+    for (int r = ty; r < B; r += 8) {
+      const double v = x[(size_t)r * ld + c];
+      a += v;
+      b += v * v;
+    }
   }
+  red[0][ty][tx] = a;
+  red[1][ty][tx] = b;
+  __syncthreads();
+  a = 0.0;
+  b = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a += red[0][k][tx];
+    b += red[1][k][tx];
+  }
+  if (!ok) return;
   const double n = B, mean = a / n;
   double var = b / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const double sc = (double)gamma[c] / sqrt(var + (double)BN_EPS), sh = (double)beta[c] - mean * sc;
-  for (int r = 0; r < B; ++r) x[(size_t)r * ld + c] = (float)((double)x[(size_t)r * ld + c] * sc + sh);
+#pragma unroll 4
+  for (int r = ty; r < B; r += 8) x[(size_t)r * ld + c] = (float)((double)x[(size_t)r * ld + c] * sc + sh);
+  if (ty != 0) return;
   const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
   rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
   rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
@@ -189,7 +226,7 @@ int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, floa
   else
     hipLaunchKernelGGL(bn_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_z, ld, R, C, d_part);
   SUGAR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, s, d_part, nblk, C, (double)R,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, s, d_part, nblk, C, (double)R,
                      st.gamma(), st.beta(), st.mean(), st.var(), momentum, d_scale, d_shift);
   SUGAR_LAUNCH_CHECK();
   const int64_t items = R * (C / E);
@@ -203,7 +240,7 @@ int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, floa
 }
 
 int launch_bn_rows(float* d_x, int ld, int B, const BNState& st, float momentum, hipStream_t s) {
-  hipLaunchKernelGGL(bn_rows_kernel, dim3((unsigned)ceil_div(st.n, 256)), dim3(256), 0, s, d_x, ld, B, st.n, st.gamma(),
+  hipLaunchKernelGGL(bn_rows_kernel, dim3((unsigned)ceil_div(st.n, 32)), dim3(256), 0, s, d_x, ld, B, st.n, st.gamma(),
                      st.beta(), st.mean(), st.var(), momentum);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;

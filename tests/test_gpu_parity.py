@@ -247,7 +247,28 @@ def test_subnet_sweep_equals_one_at_a_time(meta, supernet):
                 sugar_amd.batch_forward(recal_loader, model, device=DEV)
             eer, dcf = sugar_amd.veri_validate(loader, model, device=DEV)
             key = (cfg[0], tuple(cfg[1]), tuple(cfg[2]), cfg[3])
-            assert got[key]["eer"] == eer[0] and got[key]["mindcf"] == dcf[0], (cfg, got[key], eer, dcf)
+            assert got[key]["eer"] == eer[0] and got[key]["mindcf"] == dcf[0], (recal_loader is not None, cfg, got[key], eer, dcf)
+
+
+def test_concurrent_streams_are_bit_identical(meta, supernet):
+    """extract_vectors overlaps consecutive batches on HIP streams, which puts VALU-only kernels (the FFT front-end) and
+    MFMA kernels on the same CU.  The vectors must be bit-identical to the one-stream result every time.  (With
+    packed-FP32 instructions in the library about 10 % of such runs had one utterance wrong: DESIGN.md section 5b,
+    tools/fbank_corun.hip; sugar_amd/build.py switches the feature off.)"""
+    import sugar_amd.vectors as V
+    n_utts = 48
+    lens = synth.ragged_lengths(n_utts, lo=24000, hi=40000, seed=13).tolist()
+    packed = sugar_amd.PackedUtterances(_Utts(synth.ragged_waveforms(lens, seed=13), [1] * n_utts), DEV, batch_size=4)
+    model = _model(supernet, cfg_of(meta, "odd"), "bf16")
+    saved = V.N_LANES
+    try:
+        V.N_LANES = 1
+        ref = sugar_amd.extract_vectors(model, packed).matrix.clone()
+        V.N_LANES = 4
+        bad = sum(int(not torch.equal(sugar_amd.extract_vectors(model, packed).matrix, ref)) for _ in range(60))
+    finally:
+        V.N_LANES = saved
+    assert bad == 0, "%d of 60 four-stream runs differ from the one-stream vectors" % bad
 
 
 def test_full_size_batch256_properties(supernet):

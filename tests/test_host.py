@@ -154,3 +154,12 @@ def test_batchplan_rejects_short_audio():
         BatchPlan([200], "cpu")
     p = BatchPlan([10000, 48000], "cpu")
     assert p.R == 364 and p.t_max == 301 and p.row_off.tolist() == [0, 63, 364] and p.wav_off.tolist() == [0, 10000]
+
+
+def test_library_is_built_without_packed_fp32():
+    """Packed-FP32 VALU instructions gave wrong results next to MFMA waves of another kernel on MI355X (DESIGN.md
+    section 5b): the build must keep the feature off unless explicitly overridden."""
+    import os
+    from sugar_amd import build
+    if os.environ.get("SUGAR_ALLOW_PACKED_FP32") is None:
+        assert "-packed-fp32-ops" in build.FLAGS
