@@ -56,6 +56,43 @@ def cpu_baseline(config, seconds=10.0):
             "sample": "%d forwards of 8 x 3 s (48000-sample) utterances, f32 oracle (torch CPU), %.1f s" % (n, dt)}
 
 
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def stage_roofline(stages_ms, config, B, L, R, precision):
+    """Per stage: algorithmic GFLOP and MB per step, the roofline that bounds it and the fraction
+    of that roofline the measured time reaches.  Bytes count each activation tensor once in and once out."""
+    depth, ch, ks, ccat = config
+    esz = 2 if precision == "bf16" else 4
+    c0 = ch[0]
+    w = [ch[i + 1] // 8 for i in range(depth)]
+    mid = [8 * x for x in w]
+    work = {   # stage: (flops, bytes)
+        "fbank_dft+instnorm": (0.0, 4.0 * B * L + esz * 80.0 * R),
+        "layer1": (2.0 * R * c0 * 80 * ks[0], (80.0 + c0) * R * esz),
+        "first_conv": (sum(2.0 * R * c0 * m for m in mid), sum((c0 + m) * R * esz for m in mid)),
+        "res2_steps": (sum(7 * 2.0 * R * x * x * ks[i + 1] for i, x in enumerate(w)), sum(2.0 * 7 * x * R * esz for x in w)),
+        "last_conv": (sum(2.0 * R * m * c0 for m in mid), sum((m + c0) * R * esz for m in mid)),
+        "se_scale": (0.0, depth * c0 * R * esz * 1.0),
+        "se_apply": (0.0, (4.0 * (depth - 1) + 3.0) * c0 * R * esz),
+        "catconv": (2.0 * R * depth * c0 * ccat, (depth * c0 + ccat) * R * esz * 1.0),
+        "pool_linear1": (2.0 * R * ccat * 128, (ccat + 128.0) * R * esz),
+        "pool_stats": (2.0 * R * 128 * ccat, (ccat + 128.0) * R * esz),
+    }
+    peak_tf = PEAK[precision][0]
+    out = {}
+    for name, (flops, nbytes) in work.items():
+        ms = stages_ms.get(name)
+        if not ms:
+            continue
+        t_mfma, t_hbm = flops / (peak_tf * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+        bound = "mfma" if t_mfma > t_hbm else "hbm"
+        out[name] = {"ms": ms, "gflop": round(flops / 1e9, 2), "mbytes": round(nbytes / 1e6, 1), "bound": bound,
+                     "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "gbytes_per_s": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                     "frac": round(max(t_mfma, t_hbm) / (ms * 1e-3), 3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,15 +223,20 @@ def main():
                      "note": "same steps, consecutive batches alternating over 2 HIP streams; measured after the "
                              "timed region"}
 
-    stages = None
-    if args.stages and rank == 0:
+    # after the timed region, rank 0: hipEvent brackets around every stage of 5 more steps, and each stage's algorithmic
+    # FLOPs / bytes against the MFMA and HBM peaks (north_star: "MFMA utilisation for the conv GEMMs and achieved HBM
+    # GB/s for the feature and pooling kernels, each against MI355X peak")
+    stages = stage_roof = None
+    if rank == 0:
         _lib.profile_enable((1 << _lib.STAGE_COUNT) - 1)
         for i in range(5):
             model(wav, normalize=True)
         torch.cuda.synchronize(dev)
         stages = {k: round(ms / 5, 4) for k, (n, ms) in _lib.profile_read().items()}
         _lib.profile_enable(0)
-        print("per-stage ms/step (hipEvents, 5 steps): " + json.dumps(stages), file=sys.stderr)
+        stage_roof = stage_roofline(stages, config, B, L, R, args.precision)
+        if args.stages:
+            print("per-stage ms/step (hipEvents, 5 steps): " + json.dumps(stages), file=sys.stderr)
 
     if rank == 0:
         n_cat, ms_cat = prof.get("catconv", (0, 0.0))
@@ -233,6 +275,7 @@ def main():
         }
         if stages:
             out["stages_ms"] = stages
+            out["stage_roofline"] = stage_roof
         if pipelined:
             out["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:
