@@ -106,6 +106,23 @@ def test_long_utterances_time_segments(name, precision, supernet):
         assert torch.equal(model([wavs[2], wavs[3]])[0], model([wavs[2]])[0])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_segment_boundary_lengths_match_oracle(precision, supernet, sup_state):
+    """Utterances of exactly 2, 320/321 (instance-norm chunk), 384/385 (Res2 segment), 1024/1025 (pooling segment) and
+    2048/2049 (SE segment) frames in ONE ragged batch against the CPU oracle run per utterance (the oracle itself is
+    pinned to the reference at 101-2126 frames by tests/golden/long.npz)."""
+    frames = [2, 320, 321, 384, 385, 1024, 1025, 2048, 2049]
+    lens = [(t - 1) * 160 + 37 for t in frames]
+    wavs = synth.ragged_waveforms(lens, seed=31)
+    model = _model(supernet, layout.BASE, precision)
+    emb = model([w.to(DEV) for w in wavs])
+    want = ref_cpu.embed_ragged(ref_cpu.clone_state(sup_state, layout.BASE), layout.BASE[0], wavs)
+    c, r = _cos(emb, want), _relerr(emb, want)
+    print("boundary", precision, "cos min %.6f rel L2 max %.2e" % (c.min(), r))
+    assert c.min() >= TOL[precision]
+    assert r < REL[precision]
+
+
 def test_supernet_with_active_config_equals_clone(golden, meta, supernet):
     """Reference property: sup.config = cfg; sup(x) == sup.clone(cfg)(x)."""
     cfg = cfg_of(meta, "rand0")

@@ -135,6 +135,8 @@ int main(int argc, char** argv) {
     t = timeit([&] { launch_variant<128, 256, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,256,2>", t, flop / t / 1e9);
     t = timeit([&] { launch_variant<128, 128, 3>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,128,3>", t, flop / t / 1e9);
     t = timeit([&] { launch_variant<128, 64, 3>(a, 0); }, 10);  printf("  %-18s %.4f ms  %.0f TF\n", "<128,64,3> 2WG/CU", t, flop / t / 1e9);
+    t = timeit([&] { launch_variant<128, 64, 2>(a, 0); }, 10);  printf("  %-18s %.4f ms  %.0f TF\n", "<128,64,2> 3WG/CU", t, flop / t / 1e9);
+    t = timeit([&] { launch_variant<128, 128, 2>(a, 0); }, 10); printf("  %-18s %.4f ms  %.0f TF\n", "<128,128,2> again", t, flop / t / 1e9);
   }
   return 0;
 }
