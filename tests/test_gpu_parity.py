@@ -108,10 +108,10 @@ def test_long_utterances_time_segments(name, precision, supernet):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_segment_boundary_lengths_match_oracle(precision, supernet, sup_state):
-    """Utterances of exactly 2, 320/321 (instance-norm chunk), 384/385 (Res2 segment), 1024/1025 (pooling segment) and
+    """Utterances of exactly 3, 320/321 (instance-norm chunk), 384/385 (Res2 segment), 1024/1025 (pooling segment) and
     2048/2049 (SE segment) frames in ONE ragged batch against the CPU oracle run per utterance (the oracle itself is
     pinned to the reference at 101-2126 frames by tests/golden/long.npz)."""
-    frames = [2, 320, 321, 384, 385, 1024, 1025, 2048, 2049]
+    frames = [3, 320, 321, 384, 385, 1024, 1025, 2048, 2049]
     lens = [(t - 1) * 160 + 37 for t in frames]
     wavs = synth.ragged_waveforms(lens, seed=31)
     model = _model(supernet, layout.BASE, precision)
