@@ -11,6 +11,7 @@ from .metrics import calculate_eer, calculate_mindcf
 from .models import SpeakerModel, WrappedModel, batch_forward, bn_state_dict, checkpoint2backbone, veri_validate
 from .scores import asnorm, calculate_score, score_cohorts, score_trials, snorm
 from .transforms import LogMelFbanks, PreEmphasis
+from .nas import AccuracyPredictor, ArchCoder, GPULatencyConstraint, MinimizeError, config2d, ea_solve
 from .sweep import evaluate_subnets, gather_results, shard_configs
 from .vectors import PackedUtterances, VectorTable, extract_vectors
 
@@ -18,4 +19,5 @@ __all__ = ["DynamicTDNN", "TDNNPath", "TDNNSubnet", "ecapa_tdnn", "specfic_tdnn"
            "tdnn16m4g", "tdnn26m7g", "SpeakerModel", "WrappedModel", "bn_state_dict", "checkpoint2backbone",
            "calculate_score", "score_trials", "LogMelFbanks", "PreEmphasis", "extract_vectors", "veri_validate", "batch_forward",
            "calculate_eer", "calculate_mindcf", "score_cohorts", "asnorm", "snorm", "TDNNLatency", "latency", "evaluate_subnets",
-           "shard_configs", "gather_results", "PackedUtterances", "VectorTable"]
+           "shard_configs", "gather_results", "PackedUtterances", "VectorTable",
+           "ArchCoder", "config2d", "AccuracyPredictor", "MinimizeError", "GPULatencyConstraint", "ea_solve"]
