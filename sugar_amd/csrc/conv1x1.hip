@@ -369,6 +369,181 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
   return SUGAR_OK;
 }
 
+// ---- weights-in-registers GEMM for the K = 512 convs (first_conv / last_conv of the SE-Res2 blocks) ---------------
+// With 8 k-tiles per output tile the LDS-DMA tile kernels above are latency-bound: one stage in flight per workgroup,
+// every k-step waits a full DMA round trip (65 us for 77056 x 512 x 512, MFMA-bound would be 16).  Here the WEIGHTS
+// never go through LDS: a workgroup owns a slab of 256 output channels, each of its waves keeps the [16 CM channels x
+// K] weight fragments of its channels in registers (CM K / 8 VGPRs) for the whole launch and walks a contiguous range
+// of 64-frame tiles.  Only the activations stream through LDS, as one continuous ring of [64 frames x 64 k] stages
+// (8 KiB) that runs D = 12 stages (96 KiB per CU) ahead ACROSS tile boundaries, so after the first tile no DMA latency
+// and no tile prologue is exposed, and the DMA bytes per MFMA are a quarter of the 128 x 128 tile's.  Every wave reads
+// all 64 frames of a stage (8 B-operand fragments) for its own channels.
+//   CM = 4: 4 waves, one per SIMD, 64 channels each (256 weight VGPRs of the 512 a lone wave may use)
+//   CM = 2: 8 waves, two per SIMD, 32 channels each
+// Software pipeline over 32-deep halves: while the MFMAs of one half issue, the fragments of the next are on their way
+// from LDS.  The barrier that opens stage g + 1 sits in the middle of stage g: every wave has then read all of stage g
+// (slot free for the DMA of stage g + 1 + D) and has its own rows of stage g + 1 in LDS.
+// Same sums in the same order as gemm_tile: bit-identical outputs.
+// Diagnostic builds only (tools/wreg_bench.hip with -DWREG_KNOCK=bits): leave out the MFMAs (1), the LDS fragment reads
+// (2), the activation DMA (4) or the output stores (8) to see what the kernel's time is made of; wrong results.
+#ifndef WREG_KNOCK
+#define WREG_KNOCK 0
+#endif
+constexpr int WR_TN = 64, WR_D = 12, WR_NS = WR_D + 1, WR_STAGE = WR_TN * 128;
+
+template <int KC, int CM>   // K = 64 KC; 16 CM channels per wave
+__global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(Gemm1x1Args a, int n_ftiles, int n_slabs, int P) {
+  constexpr int NW = 16 / CM, DI = 8 / NW;             // waves; DMA instructions per wave and stage
+  constexpr int EPI_STRIDE = CM * 32 + 16, EPW = WR_TN * EPI_STRIDE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  // workgroups b and b + 8 (same XCD) take the two channel slabs of one frame range: the second read of x hits L2
+  const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+  const int slab = j % n_slabs, p = xcd + 8 * (j / n_slabs);
+  const int t0 = (int)((int64_t)p * n_ftiles / P), t1 = (int)((int64_t)(p + 1) * n_ftiles / P);
+  if (t0 >= t1) return;
+  const int G = (t1 - t0) * KC;                       // stages of this workgroup
+  const int co_w = slab * 256 + wv * (CM * 16);       // first channel of this wave
+
+  // ---- activation DMA: wave wv fills rows 8 DI wv .. + 8 DI - 1 of a stage ----------------------------------------
+  const int drow = wv * (8 * DI) + (lane >> 3);
+  auto issue = [&](int slot, int tile, int ks) {
+    if (WREG_KNOCK & 4) return;
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int row = drow + 8 * i;
+      const int dchunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that belongs at LDS position lane & 7
+      const int xr = min(tile * WR_TN + row, a.R - 1);   // rows past R: any valid row, masked at the store
+      const bf16* src = a.x + (size_t)xr * a.ldx + dchunk * 8 + ks * TK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + slot * WR_STAGE + (wv * DI + i) * 1024),
+                                       16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int g = 0; g < WR_D; ++g)
+    if (g < G) issue(g, t0 + g / KC, g % KC);      // the ring fills while the weights load
+
+  // ---- weight fragments: wf[c][m] = W[co_w + 16 m + fr][32 c + 8 fq .. + 7], c = 0 .. 2 KC - 1 -----------------
+  bf16x8 wf[2 * KC][CM];
+#pragma unroll
+  for (int c = 0; c < 2 * KC; ++c)
+#pragma unroll
+    for (int m = 0; m < CM; ++m)
+      wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + m * 16 + fr) * a.ldw + c * 32 + fq * 8);
+  const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
+
+  f32x4 acc[CM][4];
+#pragma unroll
+  for (int m = 0; m < CM; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  unsigned char* ep = smem + WR_NS * WR_STAGE + wv * EPW;   // this wave's [64 frames][16 CM channels] staging
+  auto frags = [&](bf16x8 (&f)[4], int slot, int h) {
+    const unsigned char* xb = smem + slot * WR_STAGE;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      if (WREG_KNOCK & 2) asm volatile("" : "=v"(f[n]));
+      else f[n] = *(const bf16x8*)(xb + swz(n * 16 + fr, 4 * h + fq));
+    }
+  };
+  auto mfmas = [&](int c, bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int m = 0; m < CM; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (WREG_KNOCK & 1) asm volatile("" : "+v"(acc[m][n]) : "v"(wf[c][m]), "v"(f[n]));
+        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][m], f[n], acc[m][n], 0, 0, 0);
+      }
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // once: weights and the first D stages
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (WR_D < G) issue(WR_D, t0 + WR_D / KC, WR_D % KC);
+  bf16x8 f0[4], f1[4];
+  frags(f0, 0, 0);
+  int cur = 0, g = 0;
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int ks = 0; ks < KC; ++ks, ++g) {
+      const int nx = cur + 1 == WR_NS ? 0 : cur + 1;
+      frags(f1, cur, 1);
+      mfmas(2 * ks, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      // own rows of stage g + 1 have landed once at most the D - 1 younger DMAs are outstanding (epilogue stores in
+      // the count can only make the wait longer)
+      if (g + WR_D < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * DI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (g + 1 + WR_D < G) issue(cur, t + (ks + 1 + WR_D) / KC, (ks + 1 + WR_D) % KC);
+      if (g + 1 < G) frags(f0, nx, 0);
+      mfmas(2 * ks + 1, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nx;
+    }
+    // ---- epilogue of tile t: lane (fr, fq) of acc[m][n] holds frame 16 n + fr, channels 16 m + 4 fq + {0..3} ------
+#pragma unroll
+    for (int m = 0; m < CM; ++m) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (affine) {
+        sc = *(const f32x4*)(a.scale + co_w + m * 16 + 4 * fq);
+        sh = *(const f32x4*)(a.shift + co_w + m * 16 + 4 * fq);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        f32x4 v = acc[m][n];
+        acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        v = v * sc + sh;
+        if (tanh_) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        }
+        const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *(bf16x4*)(ep + (n * 16 + fr) * EPI_STRIDE + (m * 16 + 4 * fq) * 2) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = CM * 2, RPP = 64 / LPR;              // 16-byte lanes per staged row, rows per pass
+#pragma unroll
+    for (int i = 0; i < WR_TN / RPP; ++i) {
+      const int f = i * RPP + lane / LPR, ch = lane % LPR;
+      const int r = t * WR_TN + f, co = co_w + ch * 8;
+      const u32x4 v = *(const u32x4*)(ep + f * EPI_STRIDE + ch * 16);
+      if (r < a.R && co < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
+        *(u32x4*)(a.y + (size_t)r * a.ldy + co) = v;
+        if (a.y2 && co >= a.y2_from) *(u32x4*)(a.y2 + (size_t)r * a.ldy2 + co) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int KC, int CM>
+int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
+  constexpr int smem = WR_NS * WR_STAGE + (16 / CM) * WR_TN * (CM * 32 + 16);
+  static unsigned long long opted = 0;
+  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM>, smem, &opted)) return rc;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    SUGAR_HIP(hipGetDevice(&dev));
+    SUGAR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int n_slabs = (int)ceil_div(a.cout, 256), n_ftiles = (int)ceil_div(a.R, WR_TN);
+  int P = n_cu / n_slabs / 8 * 8;
+  if (P < 8) P = 8;
+  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM>), dim3(n_slabs * P), dim3(1024 / CM), smem, s, a, n_ftiles, n_slabs, P);
+  SUGAR_LAUNCH_CHECK();
+  return SUGAR_OK;
+}
+
 // dst[(r + 2 h b + h)][C] = src[r][C] for the rows of utterance b (16 bytes per thread), zeros in the h rows before
 // and after it; the last utterance's workgroups also zero the `slack` rows that close the buffer
 __global__ __launch_bounds__(256) void pad_rows_kernel(const bf16* __restrict__ src, int C, const int32_t* __restrict__ row_off,
@@ -446,6 +621,10 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // 256 x 256 tile's lower L2 traffic and DMA issue count per MFMA win.
       // (in the pipeline, in one job: first_conv + last_conv 0.404 ms with these tiles, 0.429 with the 256 x 256
       // split grid, 0.425 with its ping-pong form)
+      // K = 512: weights-in-registers kernel (a quarter of the DMA bytes per MFMA, x read once from HBM).  Same job,
+      // Base 256 x 3 s: one stream 178.4 k vs 177.0 k emb/s, two streams 199.8 k vs 191.0 k.
+      static const bool no_wreg = getenv("SUGAR_GEMM_NO_WREG") != nullptr;   // A/B switch: the tile kernel instead
+      if (!no_wreg && a.K == 512 && L.n_pad % 256 == 0) return launch_wreg<8, 2>(a, s);
       a.n_co_tiles = (int)ceil_div(L.cout, 128);
       return launch_variant<128, 128, 2>(a, s);
     }

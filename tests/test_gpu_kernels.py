@@ -71,7 +71,9 @@ def _conv_case(dtype, cin, cout, k, dil, flags, frames, with_x2, seed):
 CONV_CASES = [
     # cin, cout, k, dil, flags, frames, x2
     (80, 512, 5, 1, 3, [63], False),                      # layer1 (K = 400 -> padded K tile)
-    (512, 512, 1, 1, 3, [301, 301], False),               # first/last 1x1
+    (512, 512, 1, 1, 3, [301, 301], False),               # first/last 1x1 (weights-in-registers GEMM; most workgroups idle)
+    (512, 512, 1, 1, 3, [301] * 40, False),               # ... 189 frame tiles: 1-2 per workgroup, the ring wraps
+    (512, 512, 1, 1, 7, [1500] * 20 + [7], False),        # ... 3-4 tiles per workgroup, ragged last tile, tanh epilogue
     (64, 64, 3, 2, 3, [301, 17, 130], True),              # Res2 step, ragged utterances, addend
     (64, 64, 5, 5, 3, [301, 63], True),                   # widest halo: k 5, dilation 5
     (16, 16, 1, 3, 3, [63, 63], True),                    # narrow subnet width (padded to the 64-row tile)
