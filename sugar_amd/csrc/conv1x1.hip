@@ -374,14 +374,15 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
 // every k-step waits a full DMA round trip (65 us for 77056 x 512 x 512, MFMA-bound would be 16).  Here the WEIGHTS
 // never go through LDS: a workgroup owns a slab of 256 output channels, each of its waves keeps the [16 CM channels x
 // K] weight fragments of its channels in registers (CM K / 8 VGPRs) for the whole launch and walks a contiguous range
-// of 64-frame tiles.  Only the activations stream through LDS, as one continuous ring of [64 frames x 64 k] stages
-// (8 KiB) that runs D = 12 stages (96 KiB per CU) ahead ACROSS tile boundaries, so after the first tile no DMA latency
+// of 64-frame tiles.  Only the activations stream through LDS, as one continuous ring of stages of SK [64 frames x
+// 64 k] sub-tiles (8 KiB each) that runs 12 sub-tiles (96 KiB per CU) ahead ACROSS tile boundaries, so after the first tile no DMA latency
 // and no tile prologue is exposed, and the DMA bytes per MFMA are a quarter of the 128 x 128 tile's.  Every wave reads
 // all 64 frames of a stage (8 B-operand fragments) for its own channels.
 //   CM = 4: 4 waves, one per SIMD, 64 channels each (256 weight VGPRs of the 512 a lone wave may use)
 //   CM = 2: 8 waves, two per SIMD, 32 channels each
 // Software pipeline over 32-deep halves: while the MFMAs of one half issue, the fragments of the next are on their way
-// from LDS.  The barrier that opens stage g + 1 sits in the middle of stage g: every wave has then read all of stage g
+// from LDS.  One workgroup barrier per stage (SK = 2, 128-deep stages: 0.061 vs 0.062 ms, the barrier is ~250 clocks);
+// the barrier that opens stage g + 1 sits before the last half of stage g: every wave has then read all of stage g
 // (slot free for the DMA of stage g + 1 + D) and has its own rows of stage g + 1 in LDS.
 // Same sums in the same order as gemm_tile: bit-identical outputs.
 // Diagnostic builds only (tools/wreg_bench.hip with -DWREG_KNOCK=bits): leave out the MFMAs (1), the LDS fragment reads
@@ -389,11 +390,13 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
 #ifndef WREG_KNOCK
 #define WREG_KNOCK 0
 #endif
-constexpr int WR_TN = 64, WR_D = 12, WR_NS = WR_D + 1, WR_STAGE = WR_TN * 128;
+constexpr int WR_TN = 64, WR_SUB = WR_TN * 128;   // a [64 frames x 64 k] sub-tile: 8 KiB
 
-template <int KC, int CM>   // K = 64 KC; 16 CM channels per wave
+template <int KC, int CM, int SK>   // K = 64 KC; 16 CM channels per wave; SK sub-tiles (64 k each) per stage and barrier
 __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(Gemm1x1Args a, int n_ftiles, int n_slabs, int P) {
-  constexpr int NW = 16 / CM, DI = 8 / NW;             // waves; DMA instructions per wave and stage
+  static_assert(KC % SK == 0, "whole stages per tile");
+  constexpr int NW = 16 / CM, DI = 8 / NW;             // waves; DMA instructions per wave and sub-tile
+  constexpr int WR_D = 12 / SK, WR_NS = WR_D + 1, WR_STAGE = SK * WR_SUB, KS = KC / SK, H = 2 * SK;
   constexpr int EPI_STRIDE = CM * 32 + 16, EPW = WR_TN * EPI_STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   const int slab = j % n_slabs, p = xcd + 8 * (j / n_slabs);
   const int t0 = (int)((int64_t)p * n_ftiles / P), t1 = (int)((int64_t)(p + 1) * n_ftiles / P);
   if (t0 >= t1) return;
-  const int G = (t1 - t0) * KC;                       // stages of this workgroup
+  const int G = (t1 - t0) * KS;                       // stages of this workgroup
   const int co_w = slab * 256 + wv * (CM * 16);       // first channel of this wave
 
   // ---- activation DMA: wave wv fills rows 8 DI wv .. + 8 DI - 1 of a stage ----------------------------------------
@@ -411,19 +414,21 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   auto issue = [&](int slot, int tile, int ks) {
     if (WREG_KNOCK & 4) return;
 #pragma unroll
-    for (int i = 0; i < DI; ++i) {
-      const int row = drow + 8 * i;
-      const int dchunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that belongs at LDS position lane & 7
-      const int xr = min(tile * WR_TN + row, a.R - 1);   // rows past R: any valid row, masked at the store
-      const bf16* src = a.x + (size_t)xr * a.ldx + dchunk * 8 + ks * TK;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + slot * WR_STAGE + (wv * DI + i) * 1024),
-                                       16, 0, 0);
-    }
+    for (int sub = 0; sub < SK; ++sub)
+#pragma unroll
+      for (int i = 0; i < DI; ++i) {
+        const int row = drow + 8 * i;
+        const int dchunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that belongs at LDS position lane & 7
+        const int xr = min(tile * WR_TN + row, a.R - 1);   // rows past R: any valid row, masked at the store
+        const bf16* src = a.x + (size_t)xr * a.ldx + dchunk * 8 + (ks * SK + sub) * TK;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(smem + slot * WR_STAGE + sub * WR_SUB + (wv * DI + i) * 1024), 16, 0, 0);
+      }
   };
 #pragma unroll
   for (int g = 0; g < WR_D; ++g)
-    if (g < G) issue(g, t0 + g / KC, g % KC);      // the ring fills while the weights load
+    if (g < G) issue(g, t0 + g / KS, g % KS);      // the ring fills while the weights load
 
   // ---- weight fragments: wf[c][m] = W[co_w + 16 m + fr][32 c + 8 fq .. + 7], c = 0 .. 2 KC - 1 -----------------
   bf16x8 wf[2 * KC][CM];
@@ -441,8 +446,9 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   unsigned char* ep = smem + WR_NS * WR_STAGE + wv * EPW;   // this wave's [64 frames][16 CM channels] staging
-  auto frags = [&](bf16x8 (&f)[4], int slot, int h) {
-    const unsigned char* xb = smem + slot * WR_STAGE;
+  auto frags = [&](bf16x8 (&f)[4], int slot, int hh) {   // half hh of the stage: sub-tile hh / 2, 32-deep half hh % 2
+    const unsigned char* xb = smem + slot * WR_STAGE + (hh >> 1) * WR_SUB;
+    const int h = hh & 1;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       if (WREG_KNOCK & 2) asm volatile("" : "=v"(f[n]));
@@ -460,25 +466,28 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // once: weights and the first D stages
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (WR_D < G) issue(WR_D, t0 + WR_D / KC, WR_D % KC);
-  bf16x8 f0[4], f1[4];
-  frags(f0, 0, 0);
+  if (WR_D < G) issue(WR_D, t0 + WR_D / KS, WR_D % KS);
+  bf16x8 fb[2][4];
+  frags(fb[0], 0, 0);
   int cur = 0, g = 0;
   for (int t = t0; t < t1; ++t) {
 #pragma unroll
-    for (int ks = 0; ks < KC; ++ks, ++g) {
+    for (int ks = 0; ks < KS; ++ks, ++g) {
       const int nx = cur + 1 == WR_NS ? 0 : cur + 1;
-      frags(f1, cur, 1);
-      mfmas(2 * ks, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      // own rows of stage g + 1 have landed once at most the D - 1 younger DMAs are outstanding (epilogue stores in
+#pragma unroll
+      for (int h = 0; h + 1 < H; ++h) {
+        frags(fb[(h + 1) & 1], cur, h + 1);
+        mfmas(H * ks + h, fb[h & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // own rows of stage g + 1 have landed once at most the D - 1 younger stages are outstanding (epilogue stores in
       // the count can only make the wait longer)
-      if (g + WR_D < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * DI) : "memory");
+      if (g + WR_D < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * DI * SK) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (g + 1 + WR_D < G) issue(cur, t + (ks + 1 + WR_D) / KC, (ks + 1 + WR_D) % KC);
-      if (g + 1 < G) frags(f0, nx, 0);
-      mfmas(2 * ks + 1, f1);
+      if (g + 1 + WR_D < G) issue(cur, t + (ks + 1 + WR_D) / KS, (ks + 1 + WR_D) % KS);
+      if (g + 1 < G) frags(fb[0], nx, 0);
+      mfmas(H * ks + H - 1, fb[1]);
       __builtin_amdgcn_sched_barrier(0);
       cur = nx;
     }
@@ -525,11 +534,11 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   }
 }
 
-template <int KC, int CM>
+template <int KC, int CM, int SK>
 int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
-  constexpr int smem = WR_NS * WR_STAGE + (16 / CM) * WR_TN * (CM * 32 + 16);
+  constexpr int smem = (12 / SK + 1) * SK * WR_SUB + (16 / CM) * WR_TN * (CM * 32 + 16);
   static unsigned long long opted = 0;
-  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM>, smem, &opted)) return rc;
+  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK>, smem, &opted)) return rc;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -539,7 +548,7 @@ int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
   const int n_slabs = (int)ceil_div(a.cout, 256), n_ftiles = (int)ceil_div(a.R, WR_TN);
   int P = n_cu / n_slabs / 8 * 8;
   if (P < 8) P = 8;
-  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM>), dim3(n_slabs * P), dim3(1024 / CM), smem, s, a, n_ftiles, n_slabs, P);
+  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK>), dim3(n_slabs * P), dim3(1024 / CM), smem, s, a, n_ftiles, n_slabs, P);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
@@ -621,10 +630,13 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // 256 x 256 tile's lower L2 traffic and DMA issue count per MFMA win.
       // (in the pipeline, in one job: first_conv + last_conv 0.404 ms with these tiles, 0.429 with the 256 x 256
       // split grid, 0.425 with its ping-pong form)
-      // K = 512: weights-in-registers kernel (a quarter of the DMA bytes per MFMA, x read once from HBM).  Same job,
-      // Base 256 x 3 s: one stream 178.4 k vs 177.0 k emb/s, two streams 199.8 k vs 191.0 k.
-      static const bool no_wreg = getenv("SUGAR_GEMM_NO_WREG") != nullptr;   // A/B switch: the tile kernel instead
-      if (!no_wreg && a.K == 512 && L.n_pad % 256 == 0) return launch_wreg<8, 2>(a, s);
+      // K = 512, large R: weights-in-registers kernel (a quarter of the DMA bytes per MFMA, x read once from HBM).
+      // Same job, Base 256 x 3 s (R = 77 056): one stream 178.4 k vs 177.0 k emb/s, two streams 199.8 k vs 191.0 k.
+      // Its weight load is a fixed ~7 us per launch, so short inputs stay on the tile kernel (R = 12 040: 22 vs 15 us).
+      // SUGAR_GEMM_WREG_MIN_R moves the threshold (0: always, for the parity tests; huge: never, for A/B runs).
+      const char* min_r_env = getenv("SUGAR_GEMM_WREG_MIN_R");
+      const int64_t wreg_min_r = min_r_env ? atoll(min_r_env) : 49152;
+      if (R >= wreg_min_r && a.K == 512 && L.n_pad % 256 == 0) return launch_wreg<8, 2, 2>(a, s);
       a.n_co_tiles = (int)ceil_div(L.cout, 128);
       return launch_variant<128, 128, 2>(a, s);
     }

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
   launch_variant<128, 128, 2>(a, 0);
   a.y = y;
   CK(hipMemset(y, 0, (size_t)R * N * 2));
-  launch_wreg<8, 4>(a, 0);
+  launch_wreg<8, 2, 2>(a, 0);
   CK(hipDeviceSynchronize());
   std::vector<uint16_t> h0((size_t)R * N), h1((size_t)R * N);
   CK(hipMemcpy(h0.data(), yref, h0.size() * 2, hipMemcpyDeviceToHost));
@@ -71,9 +71,9 @@ int main(int argc, char** argv) {
   const double flop = 2.0 * R * N * K;
   for (int cold = 0; cold < 2; ++cold) {
     const float t0 = timeit([&] { launch_variant<128, 128, 2>(a, 0); }, 10, cold ? flush : nullptr);
-    const float t1 = timeit([&] { launch_wreg<8, 2>(a, 0); }, 10, cold ? flush : nullptr);
-    const float t2 = timeit([&] { launch_wreg<8, 4>(a, 0); }, 10, cold ? flush : nullptr);
-    printf("  %s  <128,128,2> %.4f ms %.0f TF   wreg 8 waves %.4f ms %.0f TF   wreg 4 waves %.4f ms %.0f TF\n", cold ? "cold" : "warm", t0,
+    const float t1 = timeit([&] { launch_wreg<8, 2, 1>(a, 0); }, 10, cold ? flush : nullptr);
+    const float t2 = timeit([&] { launch_wreg<8, 2, 2>(a, 0); }, 10, cold ? flush : nullptr);
+    printf("  %s  <128,128,2> %.4f ms %.0f TF   wreg 64-deep stages %.4f ms %.0f TF   wreg 128-deep stages %.4f ms %.0f TF\n", cold ? "cold" : "warm", t0,
            flop / t0 / 1e9, t1, flop / t1 / 1e9, t2, flop / t2 / 1e9);
   }
   return 0;
