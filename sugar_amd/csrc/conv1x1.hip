@@ -386,7 +386,7 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
 // (slot free for the DMA of stage g + 1 + D) and has its own rows of stage g + 1 in LDS.
 // Same sums in the same order as gemm_tile: bit-identical outputs.
 // Diagnostic builds only (tools/wreg_bench.hip with -DWREG_KNOCK=bits): leave out the MFMAs (1), the LDS fragment reads
-// (2), the activation DMA (4) or the output stores (8) to see what the kernel's time is made of; wrong results.
+// (2), the activation DMA (4), the output stores (8) or all but one weight-fragment address (16) to see what the kernel's time is made of; wrong results.
 #ifndef WREG_KNOCK
 #define WREG_KNOCK 0
 #endif
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   for (int c = 0; c < 2 * KC; ++c)
 #pragma unroll
     for (int m = 0; m < CM; ++m)
-      wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + m * 16 + fr) * a.ldw + c * 32 + fq * 8);
+      wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + m * 16 + fr) * a.ldw + ((WREG_KNOCK & 16) ? 0 : c * 32) + fq * 8);
   const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
 
   f32x4 acc[CM][4];
@@ -636,7 +636,9 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // SUGAR_GEMM_WREG_MIN_R moves the threshold (0: always, for the parity tests; huge: never, for A/B runs).
       const char* min_r_env = getenv("SUGAR_GEMM_WREG_MIN_R");
       const int64_t wreg_min_r = min_r_env ? atoll(min_r_env) : 49152;
-      if (R >= wreg_min_r && a.K == 512 && L.n_pad % 256 == 0) return launch_wreg<8, 2, 2>(a, s);
+      // (K = 256 .. 448 instantiations were measured on the NAS sweep, tools/sweep_bench.py: 31.5-32.7 vs 30.1-31.0 ms
+      // per subnet, so the narrower convs stay on the tile kernel)
+      if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) return launch_wreg<8, 2, 2>(a, s);
       a.n_co_tiles = (int)ceil_div(L.cout, 128);
       return launch_variant<128, 128, 2>(a, s);
     }

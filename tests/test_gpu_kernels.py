@@ -75,6 +75,8 @@ CONV_CASES = [
     (512, 512, 1, 1, 3, [301] * 40, False),               # ... 189 frame tiles: 1-2 per workgroup, the ring wraps
     (512, 512, 1, 1, 7, [1500] * 20 + [7], False),        # ... 3-4 tiles per workgroup, ragged last tile, tanh epilogue
     (512, 512, 1, 1, 3, [2048] * 25 + [1], False),        # ... R = 51201 >= the switch-over: the kernel the bench runs
+    (384, 384, 1, 1, 3, [301] * 30 + [5], False),         # narrower subnets (128 x 128 tile kernel)
+    (320, 448, 1, 1, 3, [301] * 30 + [5], False),
     (64, 64, 3, 2, 3, [301, 17, 130], True),              # Res2 step, ragged utterances, addend
     (64, 64, 5, 5, 3, [301, 63], True),                   # widest halo: k 5, dilation 5
     (16, 16, 1, 3, 3, [63, 63], True),                    # narrow subnet width (padded to the 64-row tile)
@@ -100,7 +102,7 @@ def test_conv_bf16(case):
     assert _rel(got, want) < 6e-3
 
 
-@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] == 512 and c[2] == 1],
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] == 512 and c[1] == 512 and c[2] == 1],
                          ids=lambda c: "frames%dx%d_f%d" % (len(c[5]), c[5][0], c[4]))
 def test_conv512_weights_in_registers_is_bit_identical_to_tiles(case, monkeypatch):
     """The K = 512 convs switch to gemm_wreg_kernel at R >= 49152; both kernels must give the same bits at any R."""
