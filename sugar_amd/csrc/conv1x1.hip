@@ -7,7 +7,9 @@
 // (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
 //
 //   tile      TM out channels (M, MFMA A operand = weight panel) x TN frames (N, B operand), BK = 64
-//             <256, 256, 2 stages> for the wide convs, <128, 64, 3 stages> for pooling.linear1
+//             <256, 256, 2 stages> + split tail for catconv, <128, 128, 2> for layer1 and the narrower 1x1 convs,
+//             <128, 64, 3 stages> for pooling.linear1; the 512 -> 512 convs of large batches run on gemm_wreg_kernel
+//             (weights in registers, activations through one cross-tile ring; second half of this file)
 //   waves     8 = 2 (channels) x 4 (frames); each owns TM/2 x TN/4 outputs in tiles of v_mfma_f32_16x16x32_bf16
 //   LDS       NS stages x (TM + TN) rows of 128 bytes; rows of 8 x 16-byte chunks, chunk XOR (row>>1)&7 on the
 //             per-lane SOURCE address (the DMA writes LDS lane-linearly) and the same XOR on the fragment reads
