@@ -634,10 +634,11 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // split grid, 0.425 with its ping-pong form)
       // K = 512, large R: weights-in-registers kernel (a quarter of the DMA bytes per MFMA, x read once from HBM).
       // Same job, Base 256 x 3 s (R = 77 056): one stream 178.4 k vs 177.0 k emb/s, two streams 199.8 k vs 191.0 k.
-      // Its weight load is a fixed ~7 us per launch, so short inputs stay on the tile kernel (R = 12 040: 22 vs 15 us).
+      // Its weight load is a fixed ~7 us per launch, so short inputs stay on the tile kernel (R = 12 040: 22 vs 15 us);
+      // whole forwards cross over at ~140 x 3 s (profiles/r01_wreg_threshold.log: B = 128 equal, 160 + 1 %, 384 + 6 %).
       // SUGAR_GEMM_WREG_MIN_R moves the threshold (0: always, for the parity tests; huge: never, for A/B runs).
       const char* min_r_env = getenv("SUGAR_GEMM_WREG_MIN_R");
-      const int64_t wreg_min_r = min_r_env ? atoll(min_r_env) : 49152;
+      const int64_t wreg_min_r = min_r_env ? atoll(min_r_env) : 43008;
       // (K = 256 .. 448 instantiations were measured on the NAS sweep, tools/sweep_bench.py: 31.5-32.7 vs 30.1-31.0 ms
       // per subnet, so the narrower convs stay on the tile kernel)
       if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) return launch_wreg<8, 2, 2>(a, s);
