@@ -440,6 +440,18 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
     for (int m = 0; m < CM; ++m)
       wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + m * 16 + fr) * a.ldw + ((WREG_KNOCK & 16) ? 0 : c * 32) + fq * 8);
   const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
+  // folded-BN vectors of this lane's channels, fetched once: a global load inside the tile loop would be younger than
+  // the DMA stages in flight, and waiting for it (in-order returns) would drain the ring at every tile end
+  f32x4 scp[CM], shp[CM];
+#pragma unroll
+  for (int m = 0; m < CM; ++m) {
+    scp[m] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    shp[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (affine) {
+      scp[m] = *(const f32x4*)(a.scale + co_w + m * 16 + 4 * fq);
+      shp[m] = *(const f32x4*)(a.shift + co_w + m * 16 + 4 * fq);
+    }
+  }
 
   f32x4 acc[CM][4];
 #pragma unroll
@@ -496,11 +508,7 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
     // ---- epilogue of tile t: lane (fr, fq) of acc[m][n] holds frame 16 n + fr, channels 16 m + 4 fq + {0..3} ------
 #pragma unroll
     for (int m = 0; m < CM; ++m) {
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (affine) {
-        sc = *(const f32x4*)(a.scale + co_w + m * 16 + 4 * fq);
-        sh = *(const f32x4*)(a.shift + co_w + m * 16 + 4 * fq);
-      }
+      const f32x4 sc = scp[m], sh = shp[m];
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         f32x4 v = acc[m][n];
