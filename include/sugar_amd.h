@@ -10,6 +10,12 @@
  * Conventions
  *   - plain C types only; every pointer named d_* is a DEVICE pointer owned by the caller, h_* is a HOST pointer
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued, nothing syncs
+ *   - device: entry points that take a SugarSubnet* make the subnet's device current for the call and restore the
+ *     caller's device on return; `stream` must belong to that device.  Entry points WITHOUT a subnet handle
+ *     (sugar_fbank_fwd, sugar_l2norm, the scoring calls, sugar_conv1d_fwd) run on the caller's CURRENT device, which
+ *     must be the device of `stream` and of every d_* pointer.
+ *   - threads: re-entrant per (device, stream); the only process-wide mutable state is the profiling record list
+ *     (mutex), the tunables (atomics) and per-device read-only tables built once (mutex)
  *   - return 0 on success, negative SUGAR_E* on failure; sugar_last_error() gives the per-thread message
  *   - activations are CHANNELS-LAST and PACKED over utterances: row r of a [R, C] buffer is one frame, utterance
  *     b owns rows [row_off[b], row_off[b+1]);  R = row_off[B].  There is no padding between utterances, so
@@ -239,6 +245,14 @@ int sugar_snorm_trials(const float* d_scores, const int32_t* d_enroll, const int
 int sugar_profile_enable(unsigned mask);
 int sugar_profile_read(int stage, int* count, double* total_ms);
 const char* sugar_profile_stage_name(int stage);
+
+/* Tunables for parity tests and in-job A/B runs.  No reference counterpart.  Each is read ONCE from the environment
+ * variable SUGAR_<NAME IN CAPITALS> when the library first needs one; afterwards only these calls change them
+ * (atomics: safe while other threads launch).  Names: "gemm_wreg_min_r" (default 43008: frames from which the 512-channel
+ * 1x1 convs use the weights-in-registers GEMM), "gemm_uniform", "gemm_no_pingpong", "generic_res2", "res2_max_t",
+ * "generic_layer1", "se_unfused" (switches, default 0). */
+int sugar_tune_set(const char* name, int64_t value);
+int sugar_tune_get(const char* name, int64_t* value);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,8 @@ SYMBOLS = {
     "sugar_subnet_bn_read": (_i, [_vp, _i, _fp, _fp, _i]),
     "sugar_subnet_bn_reset": (_i, [_vp]),
     "sugar_subnet_bn_commit": (_i, [_vp]),
+    "sugar_tune_set": (_i, [C.c_char_p, _i64]),
+    "sugar_tune_get": (_i, [C.c_char_p, C.POINTER(_i64)]),
 }
 
 _lib = None
@@ -99,6 +101,26 @@ def check(rc, what=""):
             raise ValueError("%s: %s" % (what or "sugar_amd", msg))
         raise SugarError("%s: %s (code %d)" % (what or "sugar_amd", msg, rc))
     return rc
+
+
+class tuned:
+    """Context manager: set library tunables (include/sugar_amd.h, sugar_tune_set) and restore them on exit."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            cur = _i64(0)
+            check(lib().sugar_tune_get(k.encode(), C.byref(cur)), "sugar_tune_get")
+            self.old[k] = cur.value
+            check(lib().sugar_tune_set(k.encode(), int(v)), "sugar_tune_set")
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            check(lib().sugar_tune_set(k.encode(), v), "sugar_tune_set")
+        return False
 
 
 STAGE_COUNT = 12

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/sugar_amd.h"
 
 namespace sugar {
@@ -46,15 +48,58 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  Function attributes are per device, so the "done" state is a
-// bit per device ordinal (one word per call site); a race between two threads only repeats the call.
-static inline int lds_opt_in(const void* fn, int bytes, unsigned long long* done_mask) {
+// bit per device ordinal (one atomic word per call site); a race between two threads only repeats the call.
+typedef std::atomic<unsigned long long> OptInMask;
+static inline int lds_opt_in(const void* fn, int bytes, OptInMask* done_mask) {
   int dev = 0;
   SUGAR_HIP(hipGetDevice(&dev));
-  if (dev >= 0 && dev < 64 && ((*done_mask >> dev) & 1ull)) return SUGAR_OK;
+  if (dev >= 0 && dev < 64 && ((done_mask->load(std::memory_order_acquire) >> dev) & 1ull)) return SUGAR_OK;
   SUGAR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  if (dev >= 0 && dev < 64) *done_mask |= 1ull << dev;
+  if (dev >= 0 && dev < 64) done_mask->fetch_or(1ull << dev, std::memory_order_release);
   return SUGAR_OK;
 }
+
+// Compute units of the CURRENT device (cached per device ordinal).
+int device_cu_count(int* n_cu);
+
+// Tunables (subnet.hip): read ONCE from the environment (SUGAR_<NAME>), afterwards only through sugar_tune_set /
+// sugar_tune_get (atomics: safe against concurrent launches).  They exist for parity tests and in-job A/B runs.
+enum {
+  TUNE_GEMM_WREG_MIN_R = 0,   // K = 512 convs use the weights-in-registers GEMM from this many frames up (43008)
+  TUNE_GEMM_UNIFORM,          // != 0: wide 1x1 convs on the uniform 256 x 256 grid (no split tail)
+  TUNE_GEMM_NO_PINGPONG,      // != 0: both waves of a SIMD in step in the wide GEMM
+  TUNE_GENERIC_RES2,          // != 0: Res2 chain as 7 generic launches
+  TUNE_RES2_MAX_T,            // frames one Res2 workgroup holds (0 = the kernel's 384)
+  TUNE_GENERIC_LAYER1,        // != 0: layer1 through the generic masked-load conv
+  TUNE_SE_UNFUSED,            // != 0: SE mean as its own pass over y instead of the last_conv epilogue sums
+  TUNE_COUNT
+};
+int64_t tune_get(int key);
+
+// Every C-ABI entry that takes a SugarSubnet* runs with the subnet's device current and restores the caller's.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define SUGAR_DEVICE_GUARD(dev)                                                                         \
+  ::sugar::DeviceGuard guard__(dev);                                                                    \
+  if (guard__.err != hipSuccess) {                                                                      \
+    ::sugar::set_error("cannot make device %d current: %s", (dev), hipGetErrorString(guard__.err));      \
+    return SUGAR_EHIP;                                                                                  \
+  }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, in
 template <int TM, int TN, int NS, int PP = 0>
 int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = NS * (TM + TN) * 128;
-  static unsigned long long opted = 0;
+  static OptInMask opted{0};
   if (int rc = lds_opt_in((const void*)gemm1x1_kernel<TM, TN, NS, PP>, smem, &opted)) return rc;
   const int grid = a.n_co_tiles * (int)ceil_div(a.R, TN);
   hipLaunchKernelGGL((gemm1x1_kernel<TM, TN, NS, PP>), dim3(grid), dim3(512), smem, s, a);
@@ -355,14 +355,10 @@ int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
 template <int PP = 0>
 int launch_split(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = 2 * (256 + 256) * 128;
-  static unsigned long long opted = 0;
+  static OptInMask opted{0};
   if (int rc = lds_opt_in((const void*)gemm1x1_split_kernel<2, PP>, smem, &opted)) return rc;
-  static int n_cu = 0;                       // every GPU of a node is the same part
-  if (!n_cu) {
-    int dev = 0;
-    SUGAR_HIP(hipGetDevice(&dev));
-    SUGAR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  int n_cu = 0;
+  if (int rc = device_cu_count(&n_cu)) return rc;
   const int total = a.n_co_tiles * (int)ceil_div(a.R, 256);
   const int n_main = total / n_cu * n_cu, tail = total - n_main;
   const int split = tail == 0 ? 1 : tail * 4 <= n_cu ? 4 : tail * 2 <= n_cu ? 2 : 1;
@@ -547,14 +543,10 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
 template <int KC, int CM, int SK>
 int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = (12 / SK + 1) * SK * WR_SUB + (16 / CM) * WR_TN * (CM * 32 + 16);
-  static unsigned long long opted = 0;
+  static OptInMask opted{0};
   if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK>, smem, &opted)) return rc;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    SUGAR_HIP(hipGetDevice(&dev));
-    SUGAR_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  int n_cu = 0;
+  if (int rc = device_cu_count(&n_cu)) return rc;
   const int n_slabs = (int)ceil_div(a.cout, 256), n_ftiles = (int)ceil_div(a.R, WR_TN);
   int P = n_cu / n_slabs / 8 * 8;
   if (P < 8) P = 8;
@@ -644,9 +636,8 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // Same job, Base 256 x 3 s (R = 77 056): one stream 178.4 k vs 177.0 k emb/s, two streams 199.8 k vs 191.0 k.
       // Its weight load is a fixed ~7 us per launch, so short inputs stay on the tile kernel (R = 12 040: 22 vs 15 us);
       // whole forwards cross over at ~140 x 3 s (profiles/r01_wreg_threshold.log: B = 128 equal, 160 + 1 %, 384 + 6 %).
-      // SUGAR_GEMM_WREG_MIN_R moves the threshold (0: always, for the parity tests; huge: never, for A/B runs).
-      const char* min_r_env = getenv("SUGAR_GEMM_WREG_MIN_R");
-      const int64_t wreg_min_r = min_r_env ? atoll(min_r_env) : 43008;
+      // The tunable gemm_wreg_min_r moves the threshold (0: always, for the parity tests; huge: never, for A/B runs).
+      const int64_t wreg_min_r = tune_get(TUNE_GEMM_WREG_MIN_R);
       // (K = 256 .. 448 instantiations were measured on the NAS sweep, tools/sweep_bench.py: 31.5-32.7 vs 30.1-31.0 ms
       // per subnet, so the narrower convs stay on the tile kernel)
       if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) return launch_wreg<8, 2, 2>(a, s);
@@ -654,8 +645,8 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       return launch_variant<128, 128, 2>(a, s);
     }
     a.n_co_tiles = (int)ceil_div(L.cout, 256);
-    static const bool uniform = getenv("SUGAR_GEMM_UNIFORM") != nullptr;   // A/B switch: no split tail
-    static const bool no_pp = getenv("SUGAR_GEMM_NO_PINGPONG") != nullptr;   // A/B switch: both waves of a SIMD in step
+    const bool uniform = tune_get(TUNE_GEMM_UNIFORM) != 0;         // A/B switch: no split tail
+    const bool no_pp = tune_get(TUNE_GEMM_NO_PINGPONG) != 0;       // A/B switch: both waves of a SIMD in step
     if (uniform) return launch_variant<256, 256, 2>(a, s);
     return no_pp ? launch_split<0>(a, s) : launch_split<1>(a, s);
   }

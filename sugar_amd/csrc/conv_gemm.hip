@@ -226,7 +226,7 @@ static int launch_conv_t(const ConvArgs& a0, hipStream_t s) {
   a.n_co_tiles = (int)ceil_div(a.cout, BCO);
   a.n_row_tiles = (int)ceil_div(a.R, BR);
   const size_t smem = 2 * (BCO + BR) * 128;
-  static unsigned long long opted = 0;   // > 64 KiB never needed here, but keep the opt-in explicit, once per device
+  static OptInMask opted{0};   // > 64 KiB never needed here, but keep the opt-in explicit, once per device
   if (int rc = lds_opt_in((const void*)conv_gemm_kernel<T, BCO, BR>, (int)smem, &opted)) return rc;
   const int grid = a.n_co_tiles * a.n_row_tiles;
   hipLaunchKernelGGL((conv_gemm_kernel<T, BCO, BR>), dim3(grid), dim3(256), smem, s, a);

@@ -42,19 +42,35 @@ struct FbankTables {
   float* mel_w = nullptr;    // [NMEL][MEL_MAXW]
 };
 
+// The tables live in file-scope __device__ arrays: every GPU the
+// library runs on holds its own copy at its own address, found once per device with hipGetSymbolAddress (in host code
+// the array NAMES are host-side stand-ins, never device addresses) and kept in g_dev.  Nothing here calls hipMalloc.
+__device__ __align__(256) float2 d_tw[NFFT];
+__device__ __align__(256) float d_win[NFFT];
+__device__ __align__(256) int d_mel_lo[NMEL];
+__device__ __align__(256) int d_mel_cnt[NMEL];
+__device__ __align__(256) float d_mel_w[NMEL * MEL_MAXW];
+
+struct DevState {
+  bool ready = false;
+  FbankTables tb;
+};
+constexpr int MAX_DEVICES = 64;
 std::mutex g_mu;
-std::vector<FbankTables> g_tables;  // indexed by device
+DevState g_dev[MAX_DEVICES];
 
 double hz_to_mel(double f) { return 2595.0 * log10(1.0 + f / 700.0); }
 double mel_to_hz(double m) { return 700.0 * (pow(10.0, m / 2595.0) - 1.0); }
 
-int get_tables(FbankTables* out) {
+// Per-device set-up, with that device current: symbol addresses + table upload.  Runs once per device, from
+// sugar_subnet_create (the library's init) or from the first front-end call on a device.
+int get_dev(DevState* out) {
   int dev = 0;
   SUGAR_HIP(hipGetDevice(&dev));
+  SUGAR_CHECK_ARG(dev >= 0 && dev < MAX_DEVICES, "fbank: device ordinal %d out of range", dev);
   std::lock_guard<std::mutex> lk(g_mu);
-  if ((int)g_tables.size() <= dev) g_tables.resize(dev + 1);
-  FbankTables& t = g_tables[dev];
-  if (!t.tw) {
+  DevState& t = g_dev[dev];
+  if (!t.ready) {
     const double PI = 3.14159265358979323846;
     std::vector<float> tw(2 * NFFT), win(NFFT, 0.f);
     for (int n = 0; n < NFFT; ++n) {
@@ -85,16 +101,19 @@ int get_tables(FbankTables* out) {
       lo[m] = first < 0 ? 0 : first;
       cnt[m] = n;
     }
-    SUGAR_HIP(hipMalloc(&t.tw, tw.size() * sizeof(float)));
-    SUGAR_HIP(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
-    SUGAR_HIP(hipMalloc(&t.win, win.size() * sizeof(float)));
-    SUGAR_HIP(hipMemcpy(t.win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
-    SUGAR_HIP(hipMalloc(&t.mel_lo, NMEL * sizeof(int)));
-    SUGAR_HIP(hipMemcpy(t.mel_lo, lo.data(), NMEL * sizeof(int), hipMemcpyHostToDevice));
-    SUGAR_HIP(hipMalloc(&t.mel_cnt, NMEL * sizeof(int)));
-    SUGAR_HIP(hipMemcpy(t.mel_cnt, cnt.data(), NMEL * sizeof(int), hipMemcpyHostToDevice));
-    SUGAR_HIP(hipMalloc(&t.mel_w, mw.size() * sizeof(float)));
-    SUGAR_HIP(hipMemcpy(t.mel_w, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
+    FbankTables tb;
+    SUGAR_HIP(hipGetSymbolAddress((void**)&tb.tw, HIP_SYMBOL(d_tw)));
+    SUGAR_HIP(hipGetSymbolAddress((void**)&tb.win, HIP_SYMBOL(d_win)));
+    SUGAR_HIP(hipGetSymbolAddress((void**)&tb.mel_lo, HIP_SYMBOL(d_mel_lo)));
+    SUGAR_HIP(hipGetSymbolAddress((void**)&tb.mel_cnt, HIP_SYMBOL(d_mel_cnt)));
+    SUGAR_HIP(hipGetSymbolAddress((void**)&tb.mel_w, HIP_SYMBOL(d_mel_w)));
+    SUGAR_HIP(hipMemcpy(tb.tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    SUGAR_HIP(hipMemcpy(tb.win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+    SUGAR_HIP(hipMemcpy(tb.mel_lo, lo.data(), NMEL * sizeof(int), hipMemcpyHostToDevice));
+    SUGAR_HIP(hipMemcpy(tb.mel_cnt, cnt.data(), NMEL * sizeof(int), hipMemcpyHostToDevice));
+    SUGAR_HIP(hipMemcpy(tb.mel_w, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
+    t.tb = tb;
+    t.ready = true;
   }
   *out = t;
   return SUGAR_OK;
@@ -421,8 +440,8 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_apply_kernel(const 
 }  // namespace
 
 int fbank_init() {
-  FbankTables t;
-  return get_tables(&t);
+  DevState t;
+  return get_dev(&t);
 }
 
 int64_t fbank_scratch_floats(int B, int64_t R) { return R * NMEL + (R / NORM_CHUNK + B + 1) * (2 * NMEL); }
@@ -432,9 +451,10 @@ int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_
   SUGAR_CHECK_ARG(d_wav && d_wav_off && d_wav_len && d_row_off && d_logmel && d_feats, "fbank: null pointer");
   SUGAR_CHECK_ARG(B > 0 && B <= 65535 && t_max > 0 && R >= t_max, "fbank: bad batch %d / t_max %d / R %lld", B, t_max, (long long)R);
   SUGAR_CHECK_ARG(dtype == SUGAR_F32 || dtype == SUGAR_BF16, "fbank: bad dtype %d", dtype);
-  FbankTables tb;
-  int rc = get_tables(&tb);
+  DevState ds;
+  int rc = get_dev(&ds);
   if (rc) return rc;
+  const FbankTables tb = ds.tb;
   hipLaunchKernelGGL(fbank_fft_kernel, dim3((unsigned)ceil_div(t_max, FRAMES), (unsigned)B), dim3(256), 0, s, d_wav,
                      d_wav_off, d_wav_len, d_row_off, tb, d_logmel);
   SUGAR_LAUNCH_CHECK();

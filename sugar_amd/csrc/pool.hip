@@ -222,7 +222,7 @@ template <typename T>
 int launch_t(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int ldh, const int32_t* d_row_off, int B,
              int t_max, float* d_pooled, float* d_part, hipStream_t s) {
   const int smem = 2 * PT * (BOTT + PC) * (int)sizeof(T);
-  static unsigned long long opted = 0;
+  static OptInMask opted{0};
   if (int rc = lds_opt_in((const void*)pool_stats_kernel<T>, smem, &opted)) return rc;
   const dim3 grid((unsigned)ceil_div(P.ccat_p, PC), (unsigned)B, (unsigned)ceil_div(t_max, POOL_SEG));
   hipLaunchKernelGGL(pool_stats_kernel<T>, grid, dim3(512), smem, s, (const T*)d_a, lda, (const T*)d_h, ldh,

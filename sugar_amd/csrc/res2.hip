@@ -327,7 +327,7 @@ int r2_smem_bytes(int t_max, int wp, int halo, int k_pad) {
 
 bool res2_chain_eligible(int dtype, int t_max, int wp, int k_pad, int n_pad) {
   if (dtype != SUGAR_BF16 || t_max < 1 || wp > 64 || wp % 8 != 0 || n_pad != 64) return false;
-  if (getenv("SUGAR_GENERIC_RES2")) return false;   // A/B switch for the parity tests: force the per-step path
+  if (tune_get(TUNE_GENERIC_RES2)) return false;    // A/B switch for the parity tests: force the per-step path
   return k_pad <= 64 * 5 && r2_smem_bytes(t_max, wp, 10, k_pad) <= 160 * 1024;
 }
 
@@ -343,8 +343,8 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   }
   const int halo = ((a.ktaps - 1) / 2) * a.dil;
   a.max_t = R2_MAX_T;
-  if (const char* e = getenv("SUGAR_RES2_MAX_T")) {      // parity tests: segment utterances the kernel could hold whole
-    const int v = atoi(e);
+  {                                                      // parity tests: segment utterances the kernel could hold whole
+    const int v = (int)tune_get(TUNE_RES2_MAX_T);
     if (v >= 128 && v <= R2_MAX_T) a.max_t = v & ~15;
   }
   a.seg_inner = (a.max_t - 2 * R2_STEPS * halo) & ~15;
@@ -362,7 +362,7 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   const bool w3 = a.k_pad <= 192;
 #define R2_CASE(M, TP, WR)                                                                                     \
   {                                                                                                            \
-    static unsigned long long opted = 0;                                                                       \
+    static OptInMask opted{0};                                                                       \
     if (int rc = lds_opt_in((const void*)res2_chain_kernel<M, TP, WR>, 160 * 1024, &opted)) return rc;         \
     hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR>), dim3(B, nseg_max), dim3(512), smem, s, a);                        \
   }

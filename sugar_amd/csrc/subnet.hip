@@ -5,8 +5,10 @@
 //          -> catconv+ReLU -> pooling.linear1+tanh -> fused linear2/softmax/statistics -> folded tail.
 // torch.cat (:662) never materialises: every block writes its output straight into its column slice of the
 // catconv input; the Res2 split/cat (:291,302) are column offsets into two [R][mid] buffers.
+#include <ctype.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -32,7 +34,8 @@ static const char* kStageNames[SUGAR_STAGE_COUNT] = {"fbank_dft+instnorm", "laye
                                                      "tail+l2norm", "rowseg"};
 struct ProfRec { int stage; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
-static unsigned g_prof_mask = 0;
+static std::atomic<unsigned> g_prof_mask{0};
+static unsigned g_prof_gen = 0;              // bumped by sugar_profile_enable: brackets opened before it are dropped
 static std::vector<ProfRec> g_prof_recs;     // recorded pairs
 static std::vector<hipEvent_t> g_prof_pool;  // reusable events
 
@@ -44,22 +47,68 @@ static hipEvent_t prof_event() {
 }
 
 struct Prof {
-  hipStream_t s; int idx = -1;
+  hipStream_t s;
+  ProfRec r{-1, nullptr, nullptr};
+  unsigned gen = 0;
   Prof(int stage, hipStream_t s_) : s(s_) {
-    if (!(g_prof_mask >> stage & 1u)) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{stage, prof_event(), prof_event()};
+    if (!(g_prof_mask.load(std::memory_order_relaxed) >> stage & 1u)) return;
+    {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      r.a = prof_event();
+      r.b = prof_event();
+      gen = g_prof_gen;
+    }
     if (!r.a || !r.b) return;
+    r.stage = stage;
     (void)hipEventRecord(r.a, s);
-    g_prof_recs.push_back(r);
-    idx = (int)g_prof_recs.size() - 1;
   }
   ~Prof() {
-    if (idx < 0) return;
+    if (r.stage < 0) return;
+    (void)hipEventRecord(r.b, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    (void)hipEventRecord(g_prof_recs[idx].b, s);
+    if (gen == g_prof_gen) g_prof_recs.push_back(r);      // the record list was not cleared in between
+    else { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
   }
 };
+
+// ---- tunables: environment read once, then atomics ----
+static const char* kTuneNames[TUNE_COUNT] = {"gemm_wreg_min_r", "gemm_uniform", "gemm_no_pingpong", "generic_res2",
+                                             "res2_max_t", "generic_layer1", "se_unfused"};
+static const int64_t kTuneDefaults[TUNE_COUNT] = {43008, 0, 0, 0, 0, 0, 0};
+static std::atomic<int64_t> g_tune[TUNE_COUNT];
+static std::once_flag g_tune_once;
+
+static void tune_init() {
+  std::call_once(g_tune_once, [] {
+    for (int k = 0; k < TUNE_COUNT; ++k) {
+      char env[64] = "SUGAR_";
+      size_t n = strlen(env);
+      for (const char* c = kTuneNames[k]; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+      env[n] = 0;
+      const char* v = getenv(env);
+      // a switch set to the empty string counts as "on", as the getenv() != nullptr tests of round 1 did
+      g_tune[k].store(v ? (*v ? atoll(v) : 1) : kTuneDefaults[k], std::memory_order_relaxed);
+    }
+  });
+}
+
+int64_t tune_get(int key) {
+  tune_init();
+  return g_tune[key].load(std::memory_order_relaxed);
+}
+
+int device_cu_count(int* n_cu) {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  SUGAR_HIP(hipGetDevice(&dev));
+  int v = dev >= 0 && dev < 64 ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (!v) {
+    SUGAR_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+  }
+  *n_cu = v;
+  return SUGAR_OK;
+}
 
 struct Block {
   ConvLayer first, res[SUGAR_RES2_SCALE - 1], last;
@@ -343,7 +392,7 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
   io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
   {
     Prof p(SUGAR_STAGE_LAYER1, s);
-    static const bool generic_l1 = getenv("SUGAR_GENERIC_LAYER1") != nullptr;   // A/B switch for the parity tests
+    const bool generic_l1 = tune_get(TUNE_GENERIC_LAYER1) != 0;                 // A/B switch for the parity tests
     if (!generic_l1 && gemm_taps_eligible(n->layer1, n->in_feats, dt))
       rc = launch_gemm_taps(n->layer1, feats, w.featp, w.S, n->c0p, row_off, B, R, t_max, s);
     else
@@ -545,21 +594,26 @@ int sugar_subnet_create(const SugarSubnetDesc* d, int dtype, int device, SugarSu
   SUGAR_CHECK_ARG(d->layer1_w && bn_ok(d->layer1_bn) && d->catconv_w && d->pool1_w && d->pool2_w && bn_ok(d->bnpool) &&
                       d->linear_w && d->linear_b && bn_ok(d->bnembed),
                   "subnet_create: null tensor");
-  SUGAR_HIP(hipSetDevice(device));
+  SUGAR_DEVICE_GUARD(device);
   SugarSubnet* n = new SugarSubnet();
   n->device = device;
-  const int rc = create(d, dtype, n);
+  int rc = create(d, dtype, n);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) {
+    set_error("subnet_create: hipDeviceSynchronize failed");
+    rc = SUGAR_EHIP;
+  }
   if (rc) {
     destroy(n);
     return rc;
   }
-  SUGAR_HIP(hipDeviceSynchronize());
   *out = n;
   return SUGAR_OK;
 }
 
 int sugar_subnet_destroy(SugarSubnet* net) {
-  if (net) destroy(net);
+  if (!net) return SUGAR_OK;
+  SUGAR_DEVICE_GUARD(net->device);
+  destroy(net);
   return SUGAR_OK;
 }
 
@@ -589,6 +643,7 @@ int sugar_tdnn_fwd(const SugarSubnet* net, const void* d_feats, const int32_t* d
                    void* d_workspace, int64_t workspace_bytes, float* d_emb, int normalize, void* stream) {
   int rc = check_fwd_args(net, d_feats, d_row_off, B, R, t_max, d_workspace, workspace_bytes, d_emb);
   if (rc) return rc;
+  SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
   return tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, (hipStream_t)stream);
 }
@@ -599,6 +654,7 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
   int rc = check_fwd_args(net, d_wav, d_row_off, B, R, t_max, d_workspace, workspace_bytes, d_emb);
   if (rc) return rc;
   SUGAR_CHECK_ARG(d_wav_off && d_wav_len, "embed_fwd: null pointer");
+  SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
   hipStream_t s = (hipStream_t)stream;
   { Prof p(SUGAR_STAGE_FBANK, s); if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, w.logmel, w.feats, net->dtype, s))) return rc; }
@@ -612,6 +668,7 @@ int sugar_tdnn_recalibrate(SugarSubnet* net, const void* d_feats, const int32_t*
   if (rc) return rc;
   SUGAR_CHECK_ARG(momentum >= 0.f && momentum <= 1.f, "recalibrate: momentum %g outside [0, 1]", momentum);
   SUGAR_CHECK_ARG(B > 1, "recalibrate: train-mode BatchNorm needs more than one utterance per batch");
+  SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
   return tdnn_recalibrate(net, d_feats, d_row_off, B, R, t_max, w, momentum, d_emb, (hipStream_t)stream);
 }
@@ -625,6 +682,7 @@ int sugar_embed_recalibrate(SugarSubnet* net, const float* d_wav, const int64_t*
   SUGAR_CHECK_ARG(d_wav_off && d_wav_len, "embed_recalibrate: null pointer");
   SUGAR_CHECK_ARG(momentum >= 0.f && momentum <= 1.f, "recalibrate: momentum %g outside [0, 1]", momentum);
   SUGAR_CHECK_ARG(B > 1, "recalibrate: train-mode BatchNorm needs more than one utterance per batch");
+  SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
   hipStream_t s = (hipStream_t)stream;
   if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, w.logmel, w.feats, net->dtype, s))) return rc;
@@ -639,7 +697,7 @@ int sugar_subnet_bn_read(SugarSubnet* net, int bn_index, float* h_mean, float* h
   BNState* st = bn_by_index(net, bn_index, &conv);
   SUGAR_CHECK_ARG(st && st->p, "bn_read: no BatchNorm %d", bn_index);
   SUGAR_CHECK_ARG(n == st->c, "bn_read: BatchNorm %d has %d channels, buffers hold %d", bn_index, st->c, n);
-  SUGAR_HIP(hipSetDevice(net->device));
+  SUGAR_DEVICE_GUARD(net->device);
   SUGAR_HIP(hipDeviceSynchronize());
   std::vector<float> v[4];
   int rc = bn_download(*st, v);
@@ -651,7 +709,7 @@ int sugar_subnet_bn_read(SugarSubnet* net, int bn_index, float* h_mean, float* h
 
 int sugar_subnet_bn_reset(SugarSubnet* net) {
   SUGAR_CHECK_ARG(net, "bn_reset: null pointer");
-  SUGAR_HIP(hipSetDevice(net->device));
+  SUGAR_DEVICE_GUARD(net->device);
   for (int i = 0; i < sugar_subnet_bn_count(net); ++i) {
     ConvLayer* conv;
     BNState* st = bn_by_index(net, i, &conv);
@@ -664,7 +722,7 @@ int sugar_subnet_bn_reset(SugarSubnet* net) {
 
 int sugar_subnet_bn_commit(SugarSubnet* net) {
   SUGAR_CHECK_ARG(net, "bn_commit: null pointer");
-  SUGAR_HIP(hipSetDevice(net->device));
+  SUGAR_DEVICE_GUARD(net->device);
   SUGAR_HIP(hipDeviceSynchronize());
   int rc;
   for (int i = 0; i < sugar_subnet_bn_count(net) - 2; ++i) {
@@ -699,6 +757,7 @@ int sugar_tdnn_tap(const SugarSubnet* net, const void* d_feats, const int32_t* d
   SUGAR_CHECK_ARG(C > 0, "tap: unknown stage %d", what);
   SUGAR_CHECK_ARG(out_elems >= rows * C, "tap: output holds %lld elements, stage needs %lld", (long long)out_elems,
                   (long long)(rows * C));
+  SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
   rc = tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, 0, what, d_out, (hipStream_t)stream);
   return rc ? rc : C;
@@ -715,16 +774,31 @@ int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, i
                      nullptr, dtype);
   if (rc) { free_conv(&L); return rc; }
   int2* rowseg = nullptr;
+  void* xpad = nullptr;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMalloc(&rowseg, R * sizeof(int2)) != hipSuccess) { free_conv(&L); set_error("conv1d: hipMalloc"); return SUGAR_EHIP; }
-  rc = launch_build_rowseg(d_row_off, B, t_max, rowseg, s);
-  if (!rc) {
-    ConvIO io;
-    io.x = d_x; io.ldx = cin; io.x2 = d_x2; io.ldx2 = cin; io.y = d_y; io.ldy = cout;
-    rc = launch_conv(L, io, rowseg, R, dtype, s);
+  // same dispatch as the forward (tdnn_forward): dilation-1 tap convs that qualify run as the LDS-DMA GEMM over
+  // overlapping rows (layer1), everything else through launch_conv
+  const bool taps = !d_x2 && !tune_get(TUNE_GENERIC_LAYER1) && gemm_taps_eligible(L, cin, dtype);
+  if (hipMalloc(&rowseg, R * sizeof(int2)) != hipSuccess ||
+      (taps && hipMalloc(&xpad, (size_t)gemm_taps_pad_rows(L, B, R) * cin * 2) != hipSuccess)) {
+    if (rowseg) (void)hipFree(rowseg);
+    free_conv(&L);
+    set_error("conv1d: hipMalloc");
+    return SUGAR_EHIP;
+  }
+  if (taps) {
+    rc = launch_gemm_taps(L, d_x, xpad, d_y, cout, d_row_off, B, R, t_max, s);
+  } else {
+    rc = launch_build_rowseg(d_row_off, B, t_max, rowseg, s);
+    if (!rc) {
+      ConvIO io;
+      io.x = d_x; io.ldx = cin; io.x2 = d_x2; io.ldx2 = cin; io.y = d_y; io.ldy = cout;
+      rc = launch_conv(L, io, rowseg, R, dtype, s);
+    }
   }
   (void)hipStreamSynchronize(s);
   (void)hipFree(rowseg);
+  if (xpad) (void)hipFree(xpad);
   free_conv(&L);
   return rc;
 }
@@ -733,7 +807,8 @@ int sugar_profile_enable(unsigned mask) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
   g_prof_recs.clear();
-  g_prof_mask = mask;
+  ++g_prof_gen;
+  g_prof_mask.store(mask, std::memory_order_relaxed);
   return SUGAR_OK;
 }
 
@@ -757,6 +832,29 @@ int sugar_profile_read(int stage, int* count, double* total_ms) {
 
 const char* sugar_profile_stage_name(int stage) {
   return (stage >= 0 && stage < SUGAR_STAGE_COUNT) ? kStageNames[stage] : "";
+}
+
+int sugar_tune_set(const char* name, int64_t value) {
+  SUGAR_CHECK_ARG(name, "tune_set: null name");
+  tune_init();
+  for (int k = 0; k < TUNE_COUNT; ++k)
+    if (!strcmp(name, kTuneNames[k])) {
+      g_tune[k].store(value, std::memory_order_relaxed);
+      return SUGAR_OK;
+    }
+  set_error("tune_set: unknown tunable '%s'", name);
+  return SUGAR_EINVAL;
+}
+
+int sugar_tune_get(const char* name, int64_t* value) {
+  SUGAR_CHECK_ARG(name && value, "tune_get: null pointer");
+  for (int k = 0; k < TUNE_COUNT; ++k)
+    if (!strcmp(name, kTuneNames[k])) {
+      *value = tune_get(k);
+      return SUGAR_OK;
+    }
+  set_error("tune_get: unknown tunable '%s'", name);
+  return SUGAR_EINVAL;
 }
 
 int sugar_l2norm(float* d_x, int64_t n, int dim, void* stream) { return launch_l2norm(d_x, n, dim, (hipStream_t)stream); }

@@ -176,6 +176,7 @@ class TDNNSubnet(nn.Module):
         for h in self._handles.values():
             _lib.lib().sugar_subnet_destroy(h)
         self._handles = {}
+        self._workspace = {}
         self._bn_dirty, self._bn_batches = None, 0
 
     def __del__(self):
@@ -233,10 +234,14 @@ class TDNNSubnet(nn.Module):
     def workspace(self, device, B, R):
         need = _lib.check(_lib.lib().sugar_workspace_bytes(self.handle(device), B, R), "sugar_workspace_bytes")
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        # one workspace per (device, stream): forwards issued on different streams may overlap on the GPU
+        # one workspace per (device, stream): forwards issued on different streams may overlap on the GPU.  Callers
+        # that rotate over streams reuse a fixed set (vectors.stream_lanes), so the table stays small; should a caller
+        # keep creating streams anyway, the oldest entries go first.
         key = (idx, torch.cuda.current_stream(device).cuda_stream)
         ws = self._workspace.get(key)
         if ws is None or ws.numel() < need:
+            while len(self._workspace) >= 8:
+                self._workspace.pop(next(iter(self._workspace)))
             self._workspace[key] = ws = torch.empty(int(need * 1.05) + 256, dtype=torch.uint8, device=device)
         return ws
 

@@ -126,40 +126,45 @@ class WrappedModel(nn.Module):
                         subnet_filename="depth/depth.ecapa-tdnn.3.512.512.512.512.5.3.3.3.1536.bn.tar",
                         feat_type="logmelfbank", feat_dim=80, model_type="tdnn8m2g", embed_dim=192,
                         precision="bf16"):
-        def resolve(name):
-            path = name if (os.path.isabs(name) or not repo_id) else os.path.join(repo_id, name)
-            if not os.path.isfile(path):
-                raise FileNotFoundError(
-                    "%s: no network in this build -- pass local files (repo_id is treated as a local directory)" % path)
-            return path
+        """(subnet, info) from a supernet checkpoint and a subnet BN file; argument names, file formats and the
+        returned `info` keys are the reference's (sugar/models/__init__.py:129-165), the files are local."""
+        front_end = _choice("feat_type", feat_type, _FRONT_ENDS)
+        backbone = _choice("model_type", model_type, _BACKBONES)
+        _choice("precision", precision, {"bf16": None, "fp32": None})
+        info = {"supernet_file": _local_file(repo_id, supernet_filename), "subnet_file": None, "subnet": None}
+        info["supernet"] = torch.load(info["supernet_file"], map_location="cpu", weights_only=True)["state_dict"]
+        transform = front_end(n_mels=feat_dim)
+        supernet = backbone(in_feats=feat_dim, out_embeds=embed_dim)
+        supernet.precision = precision
+        info["supernet_model"] = cls(SpeakerModel(supernet, transform=transform))
+        # keys of the training-time wrapper that are not ours (module.__L__.W, module.__T__.*) are ignored, as upstream
+        info["supernet_model"].load_state_dict(info["supernet"], strict=False)
+        if subnet_filename in ("", None):
+            return None, info
+        info["subnet_file"] = _local_file(repo_id, subnet_filename)
+        info["subnet"] = torch.load(info["subnet_file"], map_location="cpu", weights_only=True)
+        subnet = supernet.clone(info["subnet"]["subnet"])                # config tuple -> static subnet (:158)
+        subnet.load_state_dict(info["subnet"]["bn"], strict=False)      # recalibrated BN statistics (:159)
+        return cls(SpeakerModel(subnet, transform=transform)), info
 
-        if precision not in ("bf16", "fp32"):
-            raise ValueError(f"{precision} not in {['bf16', 'fp32']}")
-        supernet_path = resolve(supernet_filename)
-        sup_state_dict = torch.load(supernet_path, map_location="cpu", weights_only=True)["state_dict"]
-        if feat_type == "logmelfbank":
-            transform = LogMelFbanks(n_mels=feat_dim)
-        else:
-            raise ValueError(f"{feat_type} not in {['logmelfbank']}")
-        if model_type == "tdnn8m2g":
-            modelarch = tdnn8m2g(in_feats=feat_dim, out_embeds=embed_dim)
-        else:
-            raise ValueError(f"{model_type} not in {['tdnn8m2g']}")
-        modelarch.precision = precision
-        model = cls(SpeakerModel(modelarch, transform=transform))
-        model.load_state_dict(sup_state_dict, strict=False)       # module.__L__.W etc. are unexpected keys, as upstream
-        if subnet_filename not in ["", None]:
-            subnet_bn_path = resolve(subnet_filename)
-            sub_state_dict = torch.load(subnet_bn_path, map_location="cpu", weights_only=True)
-            subnet_config = sub_state_dict["subnet"]
-            subnet = model.module.__S__.clone(subnet_config)
-            subnet.load_state_dict(sub_state_dict["bn"], strict=False)
-            subnet = cls(SpeakerModel(subnet, transform=transform))
-        else:
-            subnet = subnet_bn_path = sub_state_dict = None
-        info = {"supernet_file": supernet_path, "supernet": sup_state_dict, "supernet_model": model,
-                "subnet_file": subnet_bn_path, "subnet": sub_state_dict}
-        return subnet, info
+
+_FRONT_ENDS = {"logmelfbank": LogMelFbanks}
+_BACKBONES = {"tdnn8m2g": tdnn8m2g}
+
+
+def _choice(what, value, table):
+    if value not in table:
+        raise ValueError("%s=%r: this build provides %s" % (what, value, sorted(table)))
+    return table[value]
+
+
+def _local_file(repo_id, name):
+    """There is no network here: `repo_id` is a local directory (or empty) the file name is resolved against."""
+    path = name if (os.path.isabs(name) or not repo_id) else os.path.join(repo_id, name)
+    if not os.path.isfile(path):
+        raise FileNotFoundError("%s: no network in this build -- pass local files (repo_id is treated as a local "
+                                "directory)" % path)
+    return path
 
 
 def checkpoint2backbone(state_dict):

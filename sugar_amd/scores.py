@@ -68,12 +68,22 @@ def score_trials(trials, vectors, mode="cosine", n_jobs=4):
     return scores.double().cpu().numpy(), labels, pairs
 
 
+def _fingerprint(trials):
+    """Cheap content check of a VerificationTrials-shaped list: its length and 32 sampled (label, enroll, test)."""
+    n = len(trials.labels)
+    step = max(1, n // 32)
+    return (n, tuple((trials.labels[i], trials.enrolls[i], trials.tests[i]) for i in range(0, n, step)))
+
+
 def _trial_index(trials, keys, dev):
     """(labels ndarray, [[enroll, test], ...], enroll row index, test row index on `dev`) of a trial list against the
-    utterance order `keys`.  A sweep scores the same list once per subnet, so the result is remembered on the trial
-    object when it accepts attributes (VerificationTrials does; a plain list does not)."""
-    memo = getattr(trials, "_sugar_trial_index", None)
-    if memo is not None and memo[0] is keys and memo[1] == len(trials) and memo[2] == dev:
+    utterance order `keys`.  A sweep scores the same list once per subnet, so the result is remembered -- only on
+    VerificationTrials-shaped objects (`labels` / `enrolls` / `tests` lists filled once by load_trial), keyed by the
+    file list's identity, the device and a sampled content fingerprint; plain lists are indexed every time."""
+    memo_ok = all(isinstance(getattr(trials, a, None), list) for a in ("labels", "enrolls", "tests"))
+    fp = _fingerprint(trials) if memo_ok else None
+    memo = getattr(trials, "_sugar_trial_index", None) if memo_ok else None
+    if memo is not None and memo[0] is keys and memo[1] == fp and memo[2] == dev:
         return memo[3]
     index = {k: i for i, k in enumerate(keys)}
     labels, pairs, e_idx, t_idx = [], [], [], []
@@ -84,10 +94,8 @@ def _trial_index(trials, keys, dev):
         t_idx.append(index[tr["test"]])
     out = (np.array(labels), pairs, torch.from_numpy(np.asarray(e_idx, dtype=np.int32)).to(dev),
            torch.from_numpy(np.asarray(t_idx, dtype=np.int32)).to(dev))
-    try:
-        trials._sugar_trial_index = (keys, len(trials), dev, out)     # `keys is` the packed list's file list
-    except AttributeError:
-        pass
+    if memo_ok:
+        trials._sugar_trial_index = (keys, fp, dev, out)      # `keys is` the packed list's file list
     return out
 
 

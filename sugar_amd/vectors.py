@@ -38,6 +38,17 @@ def plan_batches(lengths, batch_size, max_frames):
 
 
 N_LANES = 2      # concurrent HIP streams of extract_vectors
+_LANES = {}      # device index -> the streams, created once (a subnet keeps one workspace per (device, stream))
+
+
+def stream_lanes(device, n=None):
+    """The first ``n`` (default N_LANES) of this process's extraction streams on ``device``, created on first use."""
+    n = N_LANES if n is None else n
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    lanes = _LANES.setdefault(idx, [])
+    while len(lanes) < n:
+        lanes.append(torch.cuda.Stream(device))
+    return lanes[:n]
 
 
 class VectorTable(dict):
@@ -51,6 +62,7 @@ class VectorTable(dict):
     def __init__(self, files, counts, matrix):
         super().__init__()
         self.files = files
+        self.counts = list(counts)
         self.matrix = matrix
         seg, start = [0], 0
         for f, n in zip(files, counts):            # segments of one file are contiguous rows
@@ -92,14 +104,47 @@ class PackedUtterances:
         return len(self.files)
 
 
-def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_size=1, max_frames=262144):
+def _dist_info(rank, world_size):
+    """(rank, world) of this call: the explicit arguments, else the initialised process group, else (0, 1)."""
+    if world_size is not None:
+        return (0 if rank is None else int(rank)), int(world_size)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class _Subset:
+    """The items `indices` of a dataset, in that order (a rank's shard)."""
+
+    def __init__(self, data, indices):
+        self.data, self.indices = data, indices
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, i):
+        return self.data[self.indices[i]]
+
+
+def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_size=1, max_frames=262144,
+                    rank=None, world_size=None):
     """
     model   : WrappedModel / SpeakerModel from sugar_amd.models
     datalst : an indexable dataset of {"file": str, "input": Tensor[n_seg, L] or [L]} (sugar/database.py:136-142),
               or a PackedUtterances built from one (then `device`, `batch_size`, `max_frames` are the packing's)
     n_jobs  : kept for signature parity (the reference's joblib threads / DataLoader workers); unused
+    rank, world_size : multi-GPU extraction (BASELINE config 4).  Default: the initialised torch.distributed process
+              group if there is one, else a single rank.  With more than one rank every rank embeds a shard of the
+              list (the reference's "GPU g takes items g, g+N, ..." striding, scripts/train_vox2_veri.py:385-403;
+              longest-first round-robin when the dataset exposes `lengths`), the shards are exchanged with ONE
+              all-gather of the [n_local, 192] blocks (RCCL over xGMI; gloo in tests) and EVERY rank returns the
+              complete table, rows and files in the order of `datalst` -- bit-identical to the one-rank result.
     Returns a VectorTable: {file: Tensor[n_seg, 192]} on the device.
     """
+    rank, world = _dist_info(rank, world_size)
+    if world > 1:
+        return _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank, world)
     packed = datalst if isinstance(datalst, PackedUtterances) else None
     device = packed.device if packed is not None else torch.device(device)
     if device.type != "cuda":
@@ -111,7 +156,7 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
     # of one batch run under the MFMA-bound kernels of the other (+9 % on 256 x 3 s batches) and the host-to-device
     # copies of the next batch overlap the compute of the current one
     main = torch.cuda.current_stream(device)
-    lanes = [torch.cuda.Stream(device) for _ in range(N_LANES)]
+    lanes = stream_lanes(device)
     for lane in lanes:
         lane.wait_stream(main)
     if packed is not None:
@@ -119,7 +164,7 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
         out = torch.empty(packed.n_rows, 192, dtype=torch.float32, device=device)
         sub = spk._subnet()
         for k, (idx, flat, plan) in enumerate(packed.batches):
-            with torch.cuda.stream(lanes[k % N_LANES]):
+            with torch.cuda.stream(lanes[k % len(lanes)]):
                 out[idx] = spk._embed_flat(sub, flat, plan, bool(norm))
     else:
         files, counts, segs = [], [], []
@@ -132,7 +177,7 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
         lengths = [int(s.numel()) for s in segs]
         out = torch.empty(len(segs), 192, dtype=torch.float32, device=device)
         for k, batch in enumerate(plan_batches(lengths, max(1, batch_size), max_frames)):
-            with torch.cuda.stream(lanes[k % N_LANES]):
+            with torch.cuda.stream(lanes[k % len(lanes)]):
                 wavs = [segs[i].to(device, non_blocking=True) for i in batch]
                 emb = spk.embed_ragged(wavs, normalize=bool(norm))
                 out[torch.tensor(batch, device=device)] = emb
@@ -141,26 +186,94 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
     return VectorTable(files, counts, out)
 
 
+def _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank, world):
+    """extract_vectors on `world` ranks: shard -> embed -> one all-gather -> the complete table on every rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != world:
+        raise _lib.SugarError("extract_vectors(world_size=%d) needs an initialised torch.distributed process group of "
+                              "that size (backend 'nccl' = RCCL on the GPUs)" % world)
+    if isinstance(datalst, PackedUtterances):
+        # the list is already on this rank's GPU in length-sorted batches: deal the batches round-robin (neighbouring
+        # batches have neighbouring lengths, so the shards balance); every rank knows every rank's rows
+        packed, device = datalst, datalst.device
+        model.to(device)
+        model.eval()
+        spk = model.module if hasattr(model, "module") else model
+        sub = spk._subnet()
+        main = torch.cuda.current_stream(device)
+        lanes = stream_lanes(device)
+        for lane in lanes:
+            lane.wait_stream(main)
+        mine = [k for k in range(len(packed.batches)) if k % world == rank]
+        parts = []
+        for j, k in enumerate(mine):
+            idx, flat, plan = packed.batches[k]
+            with torch.cuda.stream(lanes[j % len(lanes)]):
+                parts.append(spk._embed_flat(sub, flat, plan, bool(norm)))
+        for lane in lanes:
+            main.wait_stream(lane)
+        local = torch.cat(parts) if parts else torch.empty(0, 192, dtype=torch.float32, device=device)
+        blocks = gather_vectors(local, world)
+        out = torch.empty(packed.n_rows, 192, dtype=torch.float32, device=device)
+        for r in range(world):
+            rows = [packed.batches[k][0] for k in range(len(packed.batches)) if k % world == r]
+            if rows:
+                out[torch.cat(rows)] = blocks[r].to(device)
+        return VectorTable(packed.files, packed.counts, out)
+    n = len(datalst)
+    mine = shard_indices(n, rank, world, getattr(datalst, "lengths", None))
+    local = extract_vectors(model, _Subset(datalst, mine), norm, device, 0, batch_size, max_frames, rank=0, world_size=1)
+    meta = [None] * world
+    dist.all_gather_object(meta, (mine, local.files, local.counts))      # host-side bookkeeping: names + segment counts
+    blocks = gather_vectors(local.matrix, world)
+    return VectorTable(*assemble_shards(n, meta, blocks, local.matrix.device))
+
+
+def assemble_shards(n, meta, blocks, device):
+    """
+    Put gathered shards back into list order.  meta[r] = (item indices, files, segment counts) of rank r's shard,
+    blocks[r] = its [rows, D] vectors (items in that order, an item's segments contiguous).  Returns (files, counts,
+    matrix) for VectorTable: item i of the original list owns rows seg_off[i] .. seg_off[i+1] of `matrix`.
+    """
+    files, counts, src = [None] * n, [0] * n, [None] * n
+    for r, (idx, fl, ct) in enumerate(meta):
+        off = 0
+        for i, f, c in zip(idx, fl, ct):
+            files[i], counts[i], src[i] = f, c, (r, off)
+            off += c
+    if any(f is None for f in files):
+        raise _lib.SugarError("extract_vectors: the ranks' shards do not cover the list")
+    base, acc = [], 0
+    for b in blocks:
+        base.append(acc)
+        acc += b.shape[0]
+    perm = [base[r] + off + j for (r, off), c in zip(src, counts) for j in range(c)]
+    matrix = torch.cat([b.to(device) for b in blocks])[torch.tensor(perm, dtype=torch.int64, device=device)]
+    return files, counts, matrix
+
+
 def gather_vectors(local, world_size=None):
     """
     Multi-GPU exchange step: every rank embedded a shard of the utterances; one all-gather of the
     [n_local, 192] float32 blocks (RCCL over xGMI on GPUs, gloo in CPU tests) gives every rank all vectors.
     ``local``: Tensor [n_local, D]; shards may differ in size (padded to the max for the collective).
-    Returns the list of per-rank tensors in rank order.
+    Returns the list of per-rank tensors in rank order (on ``local``'s device).
     """
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [local]
     world = dist.get_world_size() if world_size is None else world_size
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    # a gloo group moves host memory: stage device tensors through the host (tests; two ranks sharing one GPU)
+    wire = local.cpu() if (local.is_cuda and dist.get_backend() == "gloo") else local
+    n = torch.tensor([wire.shape[0]], dtype=torch.int64, device=wire.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
     m = max(sizes)
-    pad = local if local.shape[0] == m else torch.cat([local, local.new_zeros(m - local.shape[0], local.shape[1])])
-    buf = local.new_empty(world * m, local.shape[1])
+    pad = wire if wire.shape[0] == m else torch.cat([wire, wire.new_zeros(m - wire.shape[0], wire.shape[1])])
+    buf = wire.new_empty(world * m, wire.shape[1])
     dist.all_gather_into_tensor(buf, pad.contiguous())
-    return [buf[r * m:r * m + sizes[r]] for r in range(world)]
+    return [buf[r * m:r * m + sizes[r]].to(local.device) for r in range(world)]
 
 
 def shard_indices(n_items, rank, world, weights=None):

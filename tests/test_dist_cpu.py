@@ -7,7 +7,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from sugar_amd import synth
-from sugar_amd.vectors import gather_vectors, shard_indices
+from sugar_amd.vectors import assemble_shards, gather_vectors, shard_indices
 
 
 def _free_port():
@@ -49,6 +49,40 @@ def test_allgather_uneven_shards_world2():
     for rank, ok, sizes in res:
         assert ok, rank
         assert sizes == [19, 18]
+
+
+def _assemble_worker(rank, world, port, n_utts, q):
+    """The exchange + reassembly of the sharded extract_vectors (vectors._extract_sharded) on stand-in vectors:
+    strided shards as in the reference (train_vox2_veri.py:385-403), 1-3 segments per utterance."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts = [1 + (i * 7) % 3 for i in range(n_utts)]
+    seg_off = [0]
+    for c in counts:
+        seg_off.append(seg_off[-1] + c)
+    table = synth.normal("dist/segs", (seg_off[-1], 192), seed=6)
+    mine = shard_indices(n_utts, rank, world)
+    local = torch.cat([table[seg_off[i]:seg_off[i + 1]] for i in mine])
+    meta = [None] * world
+    dist.all_gather_object(meta, (mine, ["utt%03d" % i for i in mine], [counts[i] for i in mine]))
+    files, got_counts, matrix = assemble_shards(n_utts, meta, gather_vectors(local, world), torch.device("cpu"))
+    ok = files == ["utt%03d" % i for i in range(n_utts)] and got_counts == counts and torch.equal(matrix, table)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_extraction_reassembles_list_order_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_assemble_worker, args=(r, 2, port, 23, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
 
 
 def test_gather_without_process_group_is_identity():

@@ -70,7 +70,8 @@ def _conv_case(dtype, cin, cout, k, dil, flags, frames, with_x2, seed):
 
 CONV_CASES = [
     # cin, cout, k, dil, flags, frames, x2
-    (80, 512, 5, 1, 3, [63], False),                      # layer1 (K = 400 -> padded K tile)
+    (80, 512, 5, 1, 3, [63], False),                      # layer1 (K = 400 -> padded K tile); bf16: LDS-DMA GEMM over taps
+    (80, 512, 5, 1, 3, [301, 17, 130, 63, 2, 1], False),  # ... ragged utterances: every zero-padded boundary of the tap GEMM
     (512, 512, 1, 1, 3, [301, 301], False),               # first/last 1x1 (weights-in-registers GEMM; most workgroups idle)
     (512, 512, 1, 1, 3, [301] * 40, False),               # ... 189 frame tiles: 1-2 per workgroup, the ring wraps
     (512, 512, 1, 1, 7, [1500] * 20 + [7], False),        # ... 3-4 tiles per workgroup, ragged last tile, tanh epilogue
@@ -81,7 +82,9 @@ CONV_CASES = [
     (64, 64, 5, 5, 3, [301, 63], True),                   # widest halo: k 5, dilation 5
     (16, 16, 1, 3, 3, [63, 63], True),                    # narrow subnet width (padded to the 64-row tile)
     (24, 24, 3, 4, 3, [40, 200], False),                  # width 22 padded to 24
-    (1536, 1536, 1, 1, 1, [150], False),                  # catconv: ReLU only
+    (1536, 1536, 1, 1, 1, [150], False),                  # catconv: ReLU only (6 tiles: all in the split tail)
+    (1536, 1536, 1, 1, 1, [301] * 40, False),             # ... 288 tiles: one full round of 256 x 256 ping-pong tiles + tail
+    (2048, 1536, 1, 1, 1, [301] * 40 + [9], False),       # ... Largest's catconv (K = 2048), ragged last tile
     (1536, 128, 1, 1, 4, [129], False),                   # pooling.linear1 + tanh
     (176, 48, 1, 1, 0, [5, 1, 300], False),               # odd sizes, no epilogue, 1-frame utterance
 ]
@@ -104,14 +107,39 @@ def test_conv_bf16(case):
 
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] == 512 and c[1] == 512 and c[2] == 1],
                          ids=lambda c: "frames%dx%d_f%d" % (len(c[5]), c[5][0], c[4]))
-def test_conv512_weights_in_registers_is_bit_identical_to_tiles(case, monkeypatch):
+def test_conv512_weights_in_registers_is_bit_identical_to_tiles(case):
     """The K = 512 convs switch to gemm_wreg_kernel at R >= 43008; both kernels must give the same bits at any R."""
-    monkeypatch.setenv("SUGAR_GEMM_WREG_MIN_R", "0")
-    wreg, want = _conv_case(_lib.SUGAR_BF16, *case[:6], with_x2=False, seed=5)
-    monkeypatch.setenv("SUGAR_GEMM_WREG_MIN_R", str(1 << 40))
-    tiles, _ = _conv_case(_lib.SUGAR_BF16, *case[:6], with_x2=False, seed=5)
+    with _lib.tuned(gemm_wreg_min_r=0):
+        wreg, want = _conv_case(_lib.SUGAR_BF16, *case[:6], with_x2=False, seed=5)
+    with _lib.tuned(gemm_wreg_min_r=1 << 40):
+        tiles, _ = _conv_case(_lib.SUGAR_BF16, *case[:6], with_x2=False, seed=5)
     assert torch.equal(wreg, tiles)
     assert _rel(wreg, want) < 6e-3
+
+
+def test_wide_gemm_schedules_are_bit_identical():
+    """catconv shape with full 256 x 256 rounds: ping-pong + split tail (what the forward runs) == in-step == uniform grid."""
+    case = (1536, 1536, 1, 1, 1, [301] * 40)
+    pp, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
+    with _lib.tuned(gemm_no_pingpong=1):
+        instep, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
+    with _lib.tuned(gemm_uniform=1):
+        uniform, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
+    assert torch.equal(pp, instep) and torch.equal(pp, uniform)
+    assert _rel(pp, want) < 6e-3
+
+
+@pytest.mark.parametrize("frames", [[63], [301, 17, 130, 63, 2, 1]], ids=["one", "ragged"])
+def test_layer1_tap_gemm_and_generic_conv_agree_with_oracle(frames):
+    """layer1 (80 -> 512, k 5) runs as an LDS-DMA GEMM over overlapping zero-padded rows; the generic masked-load conv is
+    the other implementation of the same sums.  Both against F.conv1d, and against each other."""
+    case = (80, 512, 5, 1, 3, frames)
+    gemm, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=7)
+    with _lib.tuned(generic_layer1=1):
+        generic, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=7)
+    assert _rel(gemm, want) < 6e-3 and _rel(generic, want) < 6e-3
+    # same products, different summation order (k-tile order vs tap order): only f32 reassociation + one bf16 ulp
+    assert _rel(gemm, generic) < 4e-3
 
 
 def test_conv_rejects_bad_arguments():
@@ -127,13 +155,22 @@ def test_conv_rejects_bad_arguments():
 
 
 # ------------------------------------------------------------------------------------------ front-end
+# Absolute error on instance-normalised (unit-variance) log-mel features.  The oracle itself differs from an independent
+# float64 restatement by 5e-5 (tests/test_oracle.py); the f32 FFT front-end measures 1.0e-4 .. 1.6e-4 against the oracle
+# on MI355X (printed below; the worst bins are low-energy ones, where log amplifies the f32 rounding of |X|^2), so the
+# bound is 5x the measured value.
+FBANK_TOL = 8e-4
+
+
 def test_fbank_cfg1_matches_oracle(golden):
     wav = synth.waveforms(1, 10000, seed=0)
     got = sugar_amd.LogMelFbanks()(wav.to(DEV)).cpu()
     assert got.shape == (1, 1, 80, 63)
     want = torch.from_numpy(golden["fbank/cfg1"])
-    assert (got[0, 0] - want).abs().max() < 2e-3
-    assert (got[0, 0] - ref_cpu.logmel_fbank(wav)[0, 0]).abs().max() < 2e-3
+    e1 = (got[0, 0] - want).abs().max().item()
+    e2 = (got[0, 0] - ref_cpu.logmel_fbank(wav)[0, 0]).abs().max().item()
+    print("fbank cfg1: max abs err vs golden %.2e, vs oracle %.2e (unit-variance features)" % (e1, e2))
+    assert e1 < FBANK_TOL and e2 < FBANK_TOL
 
 
 def test_fbank_batch_and_ragged_match_oracle():
@@ -142,7 +179,8 @@ def test_fbank_batch_and_ragged_match_oracle():
     got = fb(wav.to(DEV)).cpu()
     want = ref_cpu.logmel_fbank(wav)
     assert got.shape == want.shape == (5, 1, 80, 301)
-    assert (got - want).abs().max() < 2e-3
+    worst = (got - want).abs().max().item()
+    assert worst < FBANK_TOL
     # ragged: lengths straddling the 64-frame tile and the 160-sample hop; each utterance normalised on its own frames
     lens = [257, 10239, 10240, 10241, 48000, 20479, 66666]
     wavs = synth.ragged_waveforms(lens, seed=9)
@@ -152,7 +190,10 @@ def test_fbank_batch_and_ragged_match_oracle():
     for i, wv in enumerate(wavs):
         want = ref_cpu.logmel_fbank(wv.unsqueeze(0))[0, 0].t()
         assert rows[off[i]:off[i + 1]].shape == want.shape
-        assert (rows[off[i]:off[i + 1]] - want).abs().max() < 2e-3, lens[i]
+        err = (rows[off[i]:off[i + 1]] - want).abs().max().item()
+        worst = max(worst, err)
+        assert err < FBANK_TOL, (lens[i], err)
+    print("fbank batch + ragged: max abs err vs oracle %.2e" % worst)
     # bf16 output is the rounded f32 output
     rows16 = fb.rows(torch.cat(wavs).to(DEV), plan, torch.bfloat16).float().cpu()
     assert (rows16 - rows).abs().max() < 0.04
@@ -201,6 +242,45 @@ def test_stage_taps_match_reference_f32(name, golden, meta, supernet):
         assert v < 1e-4, (k, errs)
 
 
+# bf16 path, stage by stage, against the same reference module outputs.  Every stage reads bf16-rounded inputs (relative
+# rounding 2^-9 = 2e-3 per element) and the error random-walks through ~7 tensors per block, so the bound is on the
+# relative L2 error of the whole activation: 2e-2 (measured on MI355X: printed; 3e-3 at layer1 to ~9e-3 at catconv).
+# This is the per-stage check of the fast bf16 kernels (tap GEMM layer1, LDS-DMA 1x1 GEMMs, fused Res2 chain, the
+# epilogue SE sums) that the f32 test above cannot give: they only exist in bf16.
+@pytest.mark.parametrize("name", ["smallest", "odd"])
+def test_stage_taps_match_reference_bf16(name, golden, meta, supernet):
+    cfg = cfg_of(meta, name)
+    sub = supernet.clone(cfg).set_precision("bf16")
+    supernet.config = None
+    x = ref_cpu.logmel_fbank(synth.waveforms(1, 10000, seed=0)).squeeze(1)
+    feats = x[0].t().contiguous().to(torch.bfloat16).to(DEV)
+    row_off = torch.tensor([0, 63], dtype=torch.int32, device=DEV)
+    dims = sub.packed_dims()
+    depth, ch, _, ccat = cfg
+    taps = [(0, "layer1", None)]
+    for i in range(depth):
+        taps += [(1 + 4 * i, "b%d.first" % i, i), (2 + 4 * i, "b%d.res2" % i, i), (3 + 4 * i, "b%d.last" % i, i),
+                 (4 + 4 * i, "b%d.out" % i, i)]
+    taps += [(100, "catconv", None)]
+    errs = {}
+    for what, key, i in taps:
+        act, _ = sub.tap(feats, row_off, 1, 63, 63, what)
+        act = _unpack(act.float().cpu(), key.split(".")[-1], dims, i)
+        want = torch.from_numpy(golden["stage/%s/%s" % (name, key)]).t()
+        errs[key] = ((act[:, :want.shape[1]].double() - want.double()).norm() / want.double().norm()).item()
+    pooled, emb = sub.tap(feats, row_off, 1, 63, 63, 101)
+    cp = dims["ccatp"]
+    pooled = pooled.cpu()[0]
+    want = torch.from_numpy(golden["stage/%s/pool" % name])
+    got = torch.cat([pooled[:ccat], pooled[cp:cp + ccat]])
+    errs["pool"] = ((got.double() - want.double()).norm() / want.double().norm()).item()
+    want = torch.from_numpy(golden["stage/%s/embed" % name])
+    errs["embed"] = ((emb.cpu()[0].double() - want.double()).norm() / want.double().norm()).item()
+    print(name, "bf16 rel L2 per stage", {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 2e-2, (k, errs)
+
+
 # ------------------------------------------------------------------------------------------ scoring / l2norm
 def test_cosine_trials_match_calculate_score(golden, meta):
     segs = meta["score_segs"]
@@ -237,7 +317,6 @@ def test_l2norm_matches_f_normalize():
 @pytest.mark.parametrize("name", ["base", "largest", "smallest", "odd", "rand0"])
 def test_fused_res2_chain_matches_per_step_path_bf16(name, meta, supernet):
     """The one-kernel Res2 chain (res2.hip) against the 7-launch generic path, same bf16 inputs, ragged utterances."""
-    import os
     cfg = cfg_of(meta, name)
     sub = supernet.clone(cfg).set_precision("bf16")
     supernet.config = None
@@ -249,13 +328,9 @@ def test_fused_res2_chain_matches_per_step_path_bf16(name, meta, supernet):
     depth = cfg[0]
     outs = {}
     for mode in ("fused", "generic"):
-        if mode == "generic":
-            os.environ["SUGAR_GENERIC_RES2"] = "1"
-        try:
+        with _lib.tuned(generic_res2=int(mode == "generic")):
             outs[mode] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
             outs[mode].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
-        finally:
-            os.environ.pop("SUGAR_GENERIC_RES2", None)
     for i in range(depth):
         a, b = outs["fused"][i].float(), outs["generic"][i].float()
         assert torch.isfinite(a).all()
@@ -273,7 +348,6 @@ def test_res2_time_segments_are_bit_identical(name, meta, supernet):
     """Utterances cut into time segments with 7 * halo context frames (res2.hip) give exactly the bytes of the chain
     run over the whole utterance in one workgroup: SUGAR_RES2_MAX_T lowers the per-workgroup capacity so that
     utterances the kernel can hold whole (<= 384 frames) are segmented, and both runs use the same fused kernel."""
-    import os
     cfg = cfg_of(meta, name)
     sub = supernet.clone(cfg).set_precision("bf16")
     supernet.config = None
@@ -284,13 +358,9 @@ def test_res2_time_segments_are_bit_identical(name, meta, supernet):
     depth = cfg[0]
     outs = {}
     for cap in (None, "256", "160"):
-        if cap:
-            os.environ["SUGAR_RES2_MAX_T"] = cap
-        try:
+        with _lib.tuned(res2_max_t=int(cap or 0)):
             outs[cap] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
             outs[cap].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
-        finally:
-            os.environ.pop("SUGAR_RES2_MAX_T", None)
     for cap in ("256", "160"):
         for i in range(depth + 1):
             assert torch.equal(outs[None][i], outs[cap][i]), (name, cap, i)
