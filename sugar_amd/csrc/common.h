@@ -144,6 +144,7 @@ enum { EPI_RELU = 1, EPI_AFFINE = 2, EPI_TANH = 4 };
 
 struct ConvLayer {       // packed, device-resident
   void* w = nullptr;     // [n_pad][k_pad] dtype, K index = tap * cin_p + ci
+  void* wfrag = nullptr; // K = 512 bf16 1x1 convs: the same weights in gemm_wreg_kernel's fragment-load order (conv1x1.hip)
   float* scale = nullptr;  // [n_pad] (nullptr when no affine)
   float* shift = nullptr;
   int cout = 0;          // valid output channels (padded internal layout)
@@ -203,9 +204,10 @@ struct SELayer {            // device, f32, transposed for coalesced reads
   int c = 0, c_p = 0, hid = 0;
 };
 // scale[b][c] = sigmoid(W2 relu(W1 mean_t(y[b]) + b1) + b2)
-int64_t se_part_floats(int c_p, int B, int64_t R);   // d_part: segment sums of utterances longer than 2048 frames
+// d_part: se_part_floats floats, the per-(segment, channel slab) shares of the reduce layer (se_pool.hip)
+int64_t se_part_floats(const SELayer& se, int dtype, int B, int64_t R);
 int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, int t_max,
-                    float* d_mean, float* d_part, float* d_scale, int dtype, hipStream_t s);
+                    float* d_part, float* d_scale, int dtype, hipStream_t s);
 // out = y * scale[b] + S ;  S += out (skipped when d_S_out == nullptr)
 int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, void* d_S, int ldS, void* d_out,
                     int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s);

@@ -44,6 +44,7 @@ struct Gemm1x1Args {
   // run starting at padded row r + xmap * b(r), b = utterance of r (found from row_off).  xmap = 0: plain rows.
   const int32_t* row_off = nullptr;
   int B = 0, xmap = 0;
+  const bf16* wfrag = nullptr;   // gemm_wreg_kernel: the weights once more, in its fragment-load order (or nullptr)
 };
 
 constexpr int TK = 64;
@@ -390,11 +391,17 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
 #endif
 constexpr int WR_TN = 64, WR_SUB = WR_TN * 128;   // a [64 frames x 64 k] sub-tile: 8 KiB
 
+// Round 2, measured and dropped (tools/wreg_bench, R = 77 056, all bit-identical; profiles/r02_wreg_variants.log): the
+// SIMD partners (waves NW/2 ..) computing two stages (half a tile) behind the early waves so that the two waves of a
+// SIMD reach their epilogues apart: 0.058 vs 0.0505 ms warm, 0.066 vs 0.0628 cold (the ring runs two stages shorter);
+// the late waves issuing their DMA share after the first MFMA block instead of right behind the barrier: 0.0502 /
+// 0.0610 standalone, no difference in the pipeline (first_conv + last_conv 0.334 ms per step either way).  Kept from
+// that round: the weight fragments pre-packed in load order (a.wfrag): 0.0546 -> 0.0505 warm, 0.0661 -> 0.0628 cold.
 template <int KC, int CM, int SK>   // K = 64 KC; 16 CM channels per wave; SK sub-tiles (64 k each) per stage and barrier
 __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(Gemm1x1Args a, int n_ftiles, int n_slabs, int P) {
   static_assert(KC % SK == 0, "whole stages per tile");
   constexpr int NW = 16 / CM, DI = 8 / NW;             // waves; DMA instructions per wave and sub-tile
-  constexpr int WR_D = 12 / SK, WR_NS = WR_D + 1, WR_STAGE = SK * WR_SUB, KS = KC / SK, H = 2 * SK;
+  constexpr int WR_NS = 12 / SK + 1, WR_D = WR_NS - 1, WR_STAGE = SK * WR_SUB, KS = KC / SK, H = 2 * SK;
   constexpr int EPI_STRIDE = CM * 32 + 16, EPW = WR_TN * EPI_STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,8 +416,9 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
 
   // ---- activation DMA: wave wv fills rows 8 DI wv .. + 8 DI - 1 of a stage ----------------------------------------
   const int drow = wv * (8 * DI) + (lane >> 3);
-  auto issue = [&](int slot, int tile, int ks) {
+  auto issue = [&](int g) {                           // stage g of this workgroup -> slot g % WR_NS
     if (WREG_KNOCK & 4) return;
+    const int slot = g % WR_NS, tile = t0 + g / KS, ks = g % KS;
 #pragma unroll
     for (int sub = 0; sub < SK; ++sub)
 #pragma unroll
@@ -426,15 +434,25 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   };
 #pragma unroll
   for (int g = 0; g < WR_D; ++g)
-    if (g < G) issue(g, t0 + g / KS, g % KS);      // the ring fills while the weights load
+    if (g < G) issue(g);                           // the ring fills while the weights load
 
   // ---- weight fragments: wf[c][m] = W[co_w + 16 m + fr][32 c + 8 fq .. + 7], c = 0 .. 2 KC - 1 -----------------
+  // a.wfrag (packed at subnet creation): the same fragments in the order this loop reads them, so every load
+  // instruction is one contiguous KiB instead of sixteen 64-byte pieces
   bf16x8 wf[2 * KC][CM];
+  if (a.wfrag) {
+    const bf16x8* wp = (const bf16x8*)a.wfrag + ((size_t)(slab * NW + wv) * (2 * KC) * CM) * 64 + lane;
 #pragma unroll
-  for (int c = 0; c < 2 * KC; ++c)
+    for (int c = 0; c < 2 * KC; ++c)
 #pragma unroll
-    for (int m = 0; m < CM; ++m)
-      wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + m * 16 + fr) * a.ldw + ((WREG_KNOCK & 16) ? 0 : c * 32) + fq * 8);
+      for (int m = 0; m < CM; ++m) wf[c][m] = wp[(c * CM + m) * 64];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 2 * KC; ++c)
+#pragma unroll
+      for (int m = 0; m < CM; ++m)
+        wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + m * 16 + fr) * a.ldw + ((WREG_KNOCK & 16) ? 0 : c * 32) + fq * 8);
+  }
   const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
   // folded-BN vectors of this lane's channels, fetched once: a global load inside the tile loop would be younger than
   // the DMA stages in flight, and waiting for it (in-order returns) would drain the ring at every tile end
@@ -474,34 +492,7 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
         else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][m], f[n], acc[m][n], 0, 0, 0);
       }
   };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // once: weights and the first D stages
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (WR_D < G) issue(WR_D, t0 + WR_D / KS, WR_D % KS);
-  bf16x8 fb[2][4];
-  frags(fb[0], 0, 0);
-  int cur = 0, g = 0;
-  for (int t = t0; t < t1; ++t) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks, ++g) {
-      const int nx = cur + 1 == WR_NS ? 0 : cur + 1;
-#pragma unroll
-      for (int h = 0; h + 1 < H; ++h) {
-        frags(fb[(h + 1) & 1], cur, h + 1);
-        mfmas(H * ks + h, fb[h & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // own rows of stage g + 1 have landed once at most the D - 1 younger stages are outstanding (epilogue stores in
-      // the count can only make the wait longer)
-      if (g + WR_D < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * DI * SK) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (g + 1 + WR_D < G) issue(cur, t + (ks + 1 + WR_D) / KS, (ks + 1 + WR_D) % KS);
-      if (g + 1 < G) frags(fb[0], nx, 0);
-      mfmas(H * ks + H - 1, fb[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      cur = nx;
-    }
-    // ---- epilogue of tile t: lane (fr, fq) of acc[m][n] holds frame 16 n + fr, channels 16 m + 4 fq + {0..3} ------
+  auto epilogue = [&](int t) {   // tile t: lane (fr, fq) of acc[m][n] holds frame 16 n + fr, channels 16 m + 4 fq + {0..3}
 #pragma unroll
     for (int m = 0; m < CM; ++m) {
       const f32x4 sc = scp[m], sh = shp[m];
@@ -537,6 +528,35 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // once: weights and the first D stages
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (WR_D < G) issue(WR_D);
+  bf16x8 fb[2][4];
+  frags(fb[0], 0, 0);
+  int g = 0;
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks, ++g) {
+      const int cur = g % WR_NS;
+#pragma unroll
+      for (int h = 0; h + 1 < H; ++h) {
+        frags(fb[(h + 1) & 1], cur, h + 1);
+        mfmas(H * ks + h, fb[h & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // own rows of stage g + 1 have landed once at most the D - 1 younger stages are outstanding (epilogue stores in
+      // the count can only make the wait longer)
+      if (g + WR_D < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * DI * SK) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (g + 1 + WR_D < G) issue(g + 1 + WR_D);       // into the slot stage g was read from
+      if (g + 1 < G) frags(fb[0], (g + 1) % WR_NS, 0);
+      mfmas(H * ks + H - 1, fb[(H - 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    epilogue(t);
   }
 }
 
@@ -640,7 +660,10 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       const int64_t wreg_min_r = tune_get(TUNE_GEMM_WREG_MIN_R);
       // (K = 256 .. 448 instantiations were measured on the NAS sweep, tools/sweep_bench.py: 31.5-32.7 vs 30.1-31.0 ms
       // per subnet, so the narrower convs stay on the tile kernel)
-      if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) return launch_wreg<8, 2, 2>(a, s);
+      if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) {
+        a.wfrag = (const bf16*)L.wfrag;
+        return launch_wreg<8, 2, 2>(a, s);
+      }
       a.n_co_tiles = (int)ceil_div(L.cout, 128);
       return launch_variant<128, 128, 2>(a, s);
     }

@@ -294,6 +294,25 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
   }
   hipError_t e = hipMalloc(&L->w, n * esz);
   if (e == hipSuccess) e = hipMemcpy(L->w, host, n * esz, hipMemcpyHostToDevice);
+  if (e == hipSuccess && dtype == SUGAR_BF16 && k == 1 && cin_p == 512 && L->k_pad == 512 && L->n_pad % 256 == 0) {
+    // gemm_wreg_kernel<8, 2, 2> (conv1x1.hip): wave wv of channel slab `slab` loads fragment (c, m) as one contiguous
+    // KiB: lane fq * 16 + fr holds W[slab * 256 + wv * 32 + m * 16 + fr][c * 32 + fq * 8 .. + 7]
+    uint16_t* frag = (uint16_t*)malloc(n * 2);
+    if (!frag) { free(host); set_error("pack_conv: host alloc"); return SUGAR_ENOMEM; }
+    const uint16_t* src = (const uint16_t*)host;
+    size_t d = 0;
+    for (int slab = 0; slab < L->n_pad / 256; ++slab)
+      for (int wv = 0; wv < 8; ++wv)
+        for (int c = 0; c < 16; ++c)
+          for (int m = 0; m < 2; ++m)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int co = slab * 256 + wv * 32 + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
+              for (int q = 0; q < 8; ++q) frag[d++] = src[(size_t)co * 512 + kk + q];
+            }
+    e = hipMalloc(&L->wfrag, n * 2);
+    if (e == hipSuccess) e = hipMemcpy(L->wfrag, frag, n * 2, hipMemcpyHostToDevice);
+    free(frag);
+  }
   free(host);
   if (e != hipSuccess) { set_error("pack_conv: %s", hipGetErrorString(e)); return SUGAR_EHIP; }
   if (bn) {
@@ -318,6 +337,7 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
 
 void free_conv(ConvLayer* L) {
   if (L->w) (void)hipFree(L->w);
+  if (L->wfrag) (void)hipFree(L->wfrag);
   if (L->scale) (void)hipFree(L->scale);
   *L = ConvLayer();
 }

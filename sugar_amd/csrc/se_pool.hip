@@ -47,18 +47,23 @@ struct Chunk<bf16> {
 // ------------------------------------------------------------------------------------------ SE scale
 // se_mean_kernel: grid (channel slabs of 8 chunks, utterances, time segments); 256 threads = 8 chunks x 32 row lanes.
 // Utterances longer than SE_SEG frames are summed in segments of SE_SEG frames (fixed: the result does not depend on
-// the rest of the batch); the segment sums go to a table that se_mlp_kernel adds up in order.
+// the rest of the batch).  The workgroup does not stop at the channel sums: W1 (mean) is linear in the mean, so it
+// goes on to its slab's share of the reduce layer,  hpart[segment][slab][j] = sum_{c in slab} W1[j][c] sum_t y[t][c] / T,
+// 32 KiB of weights per workgroup, spread over 2 048 workgroups.  se_expand_kernel adds the shares up in a fixed
+// order.  (Round 1 ran the whole MLP as one workgroup per utterance: 512 KiB of weights per workgroup at the ~50 GB/s
+// a single CU pulls from L2 with dependent loads = 14.6 us per launch, as long as the mean pass itself.)
 constexpr int SE_SEG = 2048;
 
 __device__ __forceinline__ int se_slot(const int32_t* row_off, int b) { return row_off[b] / SE_SEG + b; }
 
 template <typename T>
-__global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, int ldy, int c_p,
-                                                      const int32_t* __restrict__ row_off,
-                                                      float* __restrict__ mean, float* __restrict__ part) {
-  constexpr int E = Chunk<T>::N;
-  __shared__ float partial[32][8 * E + 1];
-  const int b = blockIdx.y, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, int ldy, const int32_t* __restrict__ row_off,
+                                                      SELayer se, int nslab, float* __restrict__ hpart) {
+  constexpr int E = Chunk<T>::N, SC = 8 * E;          // channels per slab
+  __shared__ float partial[32][SC + 1];
+  __shared__ float msum[SC];
+  __shared__ float hp2[2][256];
+  const int b = blockIdx.y, tid = threadIdx.x, c_p = se.c_p;
   const int s_utt = row_off[b], n_utt = row_off[b + 1] - s_utt;
   const int seg0 = blockIdx.z * SE_SEG;
   if (seg0 >= n_utt) return;
@@ -81,77 +86,106 @@ __global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, i
 #pragma unroll
   for (int i = 0; i < E; ++i) partial[ty][tx * E + i] = acc[i];
   __syncthreads();
-  if (tid < 8 * E) {
-    const int c = blockIdx.x * 8 * E + tid;
-    if (c < c_p) {
-      float t = 0.f;
+  if (tid < SC) {
+    float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 32; ++k) t += partial[k][tid];
-      if (n_utt > SE_SEG) part[(size_t)(se_slot(row_off, b) + blockIdx.z) * c_p + c] = t;
-      else mean[(size_t)b * c_p + c] = t / (float)n;
+    for (int k = 0; k < 32; ++k) t += partial[k][tid];
+    msum[tid] = t / (float)n_utt;                      // this segment's share of the utterance mean
+  }
+  __syncthreads();
+  // this slab's share of reduce.weight x mean: thread (j, half) walks SC / 2 channels; weight rows of padded channels are 0
+  const int hid = se.hid, cbase = blockIdx.x * SC;
+  float* out = hpart + ((size_t)(se_slot(row_off, b) + blockIdx.z) * nslab + blockIdx.x) * hid;
+  for (int j0 = 0; j0 < hid; j0 += 128) {
+    const int j = j0 + (tid & 127), half = tid >> 7;
+    float t = 0.f;
+    if (j < hid) {
+      // no per-element condition inside the loops: hipcc would branch around every load and wait for each one; the
+      // full slab (every slab but a ragged last one) is unrolled completely so that all its loads are in flight at once
+      const int cc0 = half * (SC / 2), lim = min(SC / 2, c_p - cbase - cc0);
+      const float* __restrict__ wrow = se.w1t + (size_t)(cbase + cc0) * hid + j;
+      if (lim == SC / 2) {
+        float w[SC / 2];
+#pragma unroll
+        for (int k = 0; k < SC / 2; ++k) w[k] = wrow[(size_t)k * hid];
+#pragma unroll
+        for (int k = 0; k < SC / 2; ++k) t = fmaf(w[k], msum[cc0 + k], t);
+      } else {
+        for (int k = 0; k < lim; ++k) t = fmaf(wrow[(size_t)k * hid], msum[cc0 + k], t);
+      }
     }
+    hp2[half][tid & 127] = t;
+    __syncthreads();
+    if (tid < 128 && j < hid) out[j] = hp2[0][tid] + hp2[1][tid];
+    __syncthreads();
   }
 }
 
-// se_mlp_kernel: one 1024-thread workgroup per utterance; both tiny GEMVs split over k so no thread walks more
-// than ~64 weights, weights stored transposed so every load is coalesced.
-__global__ __launch_bounds__(1024) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ segsum,
-                                                      const int32_t* __restrict__ row_off, SELayer se,
-                                                      float* __restrict__ scale) {
-  extern __shared__ float sm[];          // mean [c_p] | hidden [hid] | partial [1024]
-  float* m = sm;
-  float* hidden = sm + se.c_p;
-  float* part = hidden + se.hid;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int n_utt = row_off[b + 1] - row_off[b];
-  if (n_utt > SE_SEG) {                              // long utterance: add up its segment sums
-    const int nseg = (n_utt + SE_SEG - 1) / SE_SEG;
-    const float* p = segsum + (size_t)se_slot(row_off, b) * se.c_p;
-    for (int c = tid; c < se.c_p; c += 1024) {
-      float t = 0.f;
-      for (int k = 0; k < nseg; ++k) t += p[(size_t)k * se.c_p + c];
-      m[c] = t / (float)n_utt;
+// se_expand_kernel: grid (groups of SE_U utterances, blocks of 64 channels), 1024 threads = 64 channels x 16 k-slices.
+// hidden = relu(b1 + the shares of every segment and slab, in order); scale = sigmoid(W2 hidden + b2) with W2 stored
+// transposed (coalesced); every weight load is used for SE_U utterances.  The arithmetic is nothing; what the kernel
+// waits for is L2 latency, so every thread issues all its loads before the first use (8 shares, <= 16 weights).
+constexpr int SE_U = 8, SE_CB = 64, SE_KP = 1024 / SE_CB;
+
+__global__ __launch_bounds__(1024) void se_expand_kernel(const float* __restrict__ hpart, const int32_t* __restrict__ row_off,
+                                                         int B, SELayer se, int nslab, float* __restrict__ scale) {
+  extern __shared__ float sm[];          // hidden [SE_U][hid] | partial [SE_U][1024]
+  float* hidden = sm;
+  float* part = sm + SE_U * se.hid;
+  const int b0 = blockIdx.x * SE_U, tid = threadIdx.x, hid = se.hid;
+  const int nu = min(SE_U, B - b0);
+  for (int idx = tid; idx < SE_U * hid; idx += 1024) {
+    const int u = idx / hid, j = idx - u * hid;
+    float t = 0.f;
+    if (u < nu) {
+      const int b = b0 + u;
+      const int n_utt = row_off[b + 1] - row_off[b];
+      const int nparts = ((n_utt + SE_SEG - 1) / SE_SEG) * nslab;
+      const float* p = hpart + (size_t)se_slot(row_off, b) * nslab * hid + j;
+      t = se.b1[j];
+      for (int k0 = 0; k0 < nparts; k0 += 8) {                          // fixed order: segment-major, then slab
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(size_t)min(k0 + k, nparts - 1) * hid];   // clamped: always a valid share
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += (k0 + k < nparts) ? v[k] : 0.f;
+      }
+      t = fmaxf(t, 0.f);
     }
-  } else {
-    for (int c = tid; c < se.c_p; c += 1024) m[c] = mean[(size_t)b * se.c_p + c];
+    hidden[idx] = t;
   }
   __syncthreads();
-  {  // hidden = relu(W1 mean + b1): thread (j, kp), kp-th slice of the channel range
-    const int KP = 1024 / se.hid > 0 ? 1024 / se.hid : 1;
-    const int j = tid % se.hid, kp = tid / se.hid;
-    float t = 0.f;
-    if (kp < KP) {
-      const int per = (se.c + KP - 1) / KP;
-      const int i0 = kp * per, i1 = min(se.c, i0 + per);
-#pragma unroll 8
-      for (int i = i0; i < i1; ++i) t = fmaf(se.w1t[(size_t)i * se.hid + j], m[i], t);
+  const int c = blockIdx.y * SE_CB + (tid & (SE_CB - 1)), kp = tid / SE_CB;
+  const int cl = min(c, se.c_p - 1);
+  float t[SE_U];
+#pragma unroll
+  for (int u = 0; u < SE_U; ++u) t[u] = 0.f;
+  const int per = (hid + SE_KP - 1) / SE_KP;
+  const int j0 = kp * per, j1 = min(hid, j0 + per);
+  for (int jb = j0; jb < j1; jb += 16) {
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = se.w2t[(size_t)min(jb + k, hid - 1) * se.c_p + cl];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float wk = (jb + k < j1) ? w[k] : 0.f;
+      const int jj = min(jb + k, hid - 1);
+#pragma unroll
+      for (int u = 0; u < SE_U; ++u) t[u] = fmaf(wk, hidden[u * hid + jj], t[u]);
     }
-    part[tid] = t;
-    __syncthreads();
-    if (tid < se.hid) {
-      float t2 = se.b1[tid];
-      for (int k = 0; k < KP; ++k) t2 += part[k * se.hid + tid];
-      hidden[tid] = fmaxf(t2, 0.f);
-    }
-    __syncthreads();
   }
-  // scale = sigmoid(W2 hidden + b2): channel blocks of 256, 4 k-slices each
-  for (int cb = 0; cb < se.c_p; cb += 256) {
-    const int c = cb + (tid & 255), kp = tid >> 8;
-    float t = 0.f;
-    if (c < se.c_p) {
-      const int per = (se.hid + 3) / 4;
-      const int j0 = kp * per, j1 = min(se.hid, j0 + per);
-#pragma unroll 8
-      for (int j = j0; j < j1; ++j) t = fmaf(se.w2t[(size_t)j * se.c_p + c], hidden[j], t);
+#pragma unroll
+  for (int u = 0; u < SE_U; ++u) part[u * 1024 + tid] = t[u];
+  __syncthreads();
+  if (tid < SE_CB && c < se.c_p) {
+    const float bias = se.b2[c];
+    for (int u = 0; u < nu; ++u) {
+      const float* pu = part + u * 1024 + tid;
+      float z = bias;
+#pragma unroll
+      for (int k = 0; k < SE_KP; ++k) z += pu[k * SE_CB];
+      scale[(size_t)(b0 + u) * se.c_p + c] = 1.0f / (1.0f + expf(-z));
     }
-    part[tid] = t;
-    __syncthreads();
-    if (tid < 256 && c < se.c_p) {
-      const float z = se.b2[c] + part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid];
-      scale[(size_t)b * se.c_p + c] = 1.0f / (1.0f + expf(-z));
-    }
-    __syncthreads();
   }
 }
 
@@ -266,24 +300,28 @@ __global__ __launch_bounds__(64) void l2norm_kernel(float* __restrict__ x, int d
 
 }  // namespace
 
-int64_t se_part_floats(int c_p, int B, int64_t R) { return (R / SE_SEG + B + 1) * (int64_t)c_p; }
+static int se_slabs(const SELayer& se, int dtype) { return (int)ceil_div(se.c_p, dtype == SUGAR_F32 ? 32 : 64); }
+
+int64_t se_part_floats(const SELayer& se, int dtype, int B, int64_t R) {
+  return (R / SE_SEG + B + 1) * (int64_t)se_slabs(se, dtype) * se.hid;
+}
 
 int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, int t_max,
-                    float* d_mean, float* d_part, float* d_scale, int dtype, hipStream_t s) {
-  SUGAR_CHECK_ARG(t_max > 0 && (t_max <= SE_SEG || d_part), "se: segment table missing (t_max %d)", t_max);
+                    float* d_part, float* d_scale, int dtype, hipStream_t s) {
+  SUGAR_CHECK_ARG(t_max > 0 && d_part, "se: partial table missing");
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(se.c_p % E == 0 && se.c_p > 0, "se: channels %d unsupported", se.c_p);
   SUGAR_CHECK_ARG(se.hid > 0 && se.hid <= 1024 && ldy % E == 0, "se: bad hidden %d / ld %d", se.hid, ldy);
-  const dim3 grid((unsigned)ceil_div(se.c_p / E, 8), (unsigned)B, (unsigned)ceil_div(t_max, SE_SEG));
+  const int nslab = se_slabs(se, dtype);
+  const dim3 grid((unsigned)nslab, (unsigned)B, (unsigned)ceil_div(t_max, SE_SEG));
   if (dtype == SUGAR_F32)
-    hipLaunchKernelGGL(se_mean_kernel<float>, grid, dim3(256), 0, s, (const float*)d_y, ldy, se.c_p, d_row_off, d_mean,
-                       d_part);
+    hipLaunchKernelGGL(se_mean_kernel<float>, grid, dim3(256), 0, s, (const float*)d_y, ldy, d_row_off, se, nslab, d_part);
   else
-    hipLaunchKernelGGL(se_mean_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_y, ldy, se.c_p, d_row_off, d_mean,
-                       d_part);
+    hipLaunchKernelGGL(se_mean_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_y, ldy, d_row_off, se, nslab, d_part);
   SUGAR_LAUNCH_CHECK();
-  const size_t smem = (se.c_p + se.hid + 1024) * sizeof(float);
-  hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(1024), smem, s, d_mean, d_part, d_row_off, se, d_scale);
+  const size_t smem = (size_t)SE_U * (se.hid + 1024) * sizeof(float);
+  hipLaunchKernelGGL(se_expand_kernel, dim3((unsigned)ceil_div(B, SE_U), (unsigned)ceil_div(se.c_p, SE_CB)), dim3(1024), smem, s,
+                     d_part, d_row_off, B, se, nslab, d_scale);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }

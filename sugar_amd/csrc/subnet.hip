@@ -334,7 +334,7 @@ struct Workspace {
   int2* rowseg;
   float* logmel;
   void *feats, *featp, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
-  float *semean, *separt, *sescale, *pooled, *poolpart, *tailpart;
+  float *separt, *sescale, *pooled, *poolpart, *tailpart;
   double* bnpart;    // recalibration: partial sums, batch (scale, shift), pre-BN embeddings
   float *bnscale, *bnshift, *embpre;
   int64_t bytes;
@@ -360,8 +360,7 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   w.ybuf = take(R * n->c0p * esz);
   w.hbuf = take(R * n->ccatp * esz);
   w.abuf = take(R * n->bott * esz);
-  w.semean = (float*)take((int64_t)B * n->c0p * 4);
-  w.separt = (float*)take(se_part_floats(n->c0p, B, R) * 4);
+  w.separt = (float*)take(se_part_floats(n->blocks[0].se, n->dtype, B, R) * 4);   // every block: same c0 / hidden
   w.sescale = (float*)take((int64_t)B * n->c0p * 4);
   w.pooled = (float*)take((int64_t)B * 2 * n->ccatp * 4);
   w.poolpart = (float*)take(pool_part_floats(n->pool, B, R) * 4);
@@ -430,7 +429,7 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
     { Prof p(SUGAR_STAGE_LAST, s); if ((rc = launch_conv(b.last, l, w.rowseg, R, dt, s))) return rc; }
     if ((rc = tapcopy(3 + 4 * i, w.ybuf, n->c0p, n->c0p))) return rc;
-    { Prof p(SUGAR_STAGE_SE_SCALE, s); if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.semean, w.separt, w.sescale, dt, s))) return rc; }
+    { Prof p(SUGAR_STAGE_SE_SCALE, s); if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.separt, w.sescale, dt, s))) return rc; }
     void* out = col(w.cat, (int64_t)i * n->c0p);
     {
       Prof p(SUGAR_STAGE_SE_APPLY, s);
@@ -511,7 +510,7 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
     l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
     if ((rc = launch_conv(raw_conv(b.last), l, w.rowseg, R, dt, s)) || (rc = bn(w.ybuf, n->c0p, n->c0p, b.bn_last)))
       return rc;
-    if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.semean, w.separt, w.sescale, dt, s))) return rc;
+    if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.separt, w.sescale, dt, s))) return rc;
     void* out = col(w.cat, (int64_t)i * n->c0p);
     if ((rc = launch_se_apply(w.ybuf, n->c0p, w.sescale, n->c0p, w.S, n->c0p, out, ldcat, i + 1 < n->depth, row_off, B,
                               t_max, dt, s)))

@@ -75,7 +75,20 @@ def ragged_lengths(n_utts: int, lo: int = 32000, hi: int = 320000, seed: int = 0
     return (lo + np.floor(u * (hi - lo + 1))).astype(np.int64)
 
 
-def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
+# The first fill of round 1 (conv gain sqrt(2), pooling.linear1 x 1, pooling.linear2 x 4): activations grow x130 through
+# the depth-4 supernet, tanh saturates and the softmax over time is nearly one-hot -- the regime in which the bf16 path
+# falls below the 0.999 cosine bar (DESIGN.md "bf16 sensitivity").  Kept as a fixture: tests/golden/round2.npz holds the
+# reference's embeddings for it, tests/test_bf16_sensitivity.py sweeps from the shipped fill (t = 0) to this one (t = 1).
+ILL_CONDITIONED = {"conv_gain": math.sqrt(2.0), "pool1_gain": 1.0, "pool2_gain": 4.0}
+
+
+def conditioning(t: float) -> dict:
+    """Fill gains on the geometric path from the shipped, trained-like fill (t = 0) to ILL_CONDITIONED (t = 1)."""
+    return {"conv_gain": 2.0 ** (0.5 * t), "pool1_gain": 0.35 ** (1.0 - t), "pool2_gain": 2.8 ** (1.0 - t) * 4.0 ** t}
+
+
+def fill_state_dict(shapes: dict, seed: int = 0, conv_gain: float = 1.0, pool1_gain: float = 0.35,
+                    pool2_gain: float = 2.8) -> dict:
     """
     Fill a {key: shape} layout (supernet or cloned-subnet naming) with deterministic values.
 
@@ -91,7 +104,8 @@ def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
                                    softmax over time clearly non-uniform (effective frames ~100-170 of 301) but not
                                    one-hot.  (With saturated tanh and one-hot softmax the pooled statistics become a
                                    discontinuous function of the activations and no reduced-precision path can track
-                                   the f32 reference; see DESIGN.md "bf16 sensitivity".)
+                                   the f32 reference; see DESIGN.md "bf16 sensitivity".)  conv_gain / pool1_gain /
+                                   pool2_gain move these three scales (defaults: the shipped fill).
       linear *.weight [O, I]     : U(+-sqrt(3 / I))
     """
     out = {}
@@ -114,9 +128,11 @@ def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
         elif leaf == "weight" and len(shape) == 3:
             a = math.sqrt(3.0 / (shape[1] * shape[2]))
             if "pooling.linear1" in key:
-                a *= 0.35
-            if "pooling.linear2" in key:
-                a *= 2.8
+                a *= pool1_gain
+            elif "pooling.linear2" in key:
+                a *= pool2_gain
+            else:
+                a *= conv_gain
             out[key] = uniform(key, shape, -a, a, seed)
         elif leaf == "weight" and len(shape) == 2:
             a = math.sqrt(3.0 / shape[1])

@@ -155,11 +155,20 @@ def test_conv_rejects_bad_arguments():
 
 
 # ------------------------------------------------------------------------------------------ front-end
-# Absolute error on instance-normalised (unit-variance) log-mel features.  The oracle itself differs from an independent
-# float64 restatement by 5e-5 (tests/test_oracle.py); the f32 FFT front-end measures 1.0e-4 .. 1.6e-4 against the oracle
-# on MI355X (printed below; the worst bins are low-energy ones, where log amplifies the f32 rounding of |X|^2), so the
-# bound is 5x the measured value.
-FBANK_TOL = 8e-4
+# Absolute error on instance-normalised (unit-variance) log-mel features.  Two oracles: the f32 restatement (torch.stft)
+# and the independent float64 one (numpy framing + rFFT); they differ from each other by up to 2.3e-4 on 3 s utterances
+# (outliers in the three lowest mel bins, which hold one or two low-energy FFT bins each: the log amplifies the f32
+# rounding of |X|^2), 6e-5 at the 99.99th percentile.  The HIP front-end (f32 radix-4 FFT) shows the same kind of outlier.
+# Measured on MI355X (printed by the tests), max over all values: vs the float64 oracle 2.8e-5 (10 000 samples), 1.1e-4
+# (5 x 3 s), 3.4e-5 .. 3.6e-4 (ragged list, worst on its 3 s entry); vs the f32 oracle 5.9e-5 / 5.4e-4 / 6e-5 .. 3.5e-4.
+# Bounds: 1e-3 against float64 (< 3x the worst measured), 1.5e-3 against the f32 oracle (< 3x).  Round 1 allowed 2e-3
+# against the f32 oracle only and did not record the measurement.
+FBANK_TOL = 1e-3            # vs the float64 oracle
+FBANK_TOL_F32 = 1.5e-3      # vs the f32 oracle (its own outliers included)
+
+
+def _fbank_f64(wav_1d):
+    return torch.from_numpy(ref_cpu.logmel_fbank_np64(wav_1d.numpy())).float()      # [80, T]
 
 
 def test_fbank_cfg1_matches_oracle(golden):
@@ -169,8 +178,9 @@ def test_fbank_cfg1_matches_oracle(golden):
     want = torch.from_numpy(golden["fbank/cfg1"])
     e1 = (got[0, 0] - want).abs().max().item()
     e2 = (got[0, 0] - ref_cpu.logmel_fbank(wav)[0, 0]).abs().max().item()
-    print("fbank cfg1: max abs err vs golden %.2e, vs oracle %.2e (unit-variance features)" % (e1, e2))
-    assert e1 < FBANK_TOL and e2 < FBANK_TOL
+    e3 = (got[0, 0] - _fbank_f64(wav[0])).abs().max().item()
+    print("fbank cfg1: max abs err vs golden %.2e, vs f32 oracle %.2e, vs f64 oracle %.2e" % (e1, e2, e3))
+    assert e1 < FBANK_TOL_F32 and e2 < FBANK_TOL_F32 and e3 < FBANK_TOL
 
 
 def test_fbank_batch_and_ragged_match_oracle():
@@ -179,8 +189,10 @@ def test_fbank_batch_and_ragged_match_oracle():
     got = fb(wav.to(DEV)).cpu()
     want = ref_cpu.logmel_fbank(wav)
     assert got.shape == want.shape == (5, 1, 80, 301)
-    worst = (got - want).abs().max().item()
-    assert worst < FBANK_TOL
+    e32 = (got - want).abs().max().item()
+    e64 = max((got[i, 0] - _fbank_f64(wav[i])).abs().max().item() for i in range(5))
+    print("fbank 5 x 3 s: max abs err vs f32 oracle %.2e, vs f64 oracle %.2e" % (e32, e64))
+    assert e32 < FBANK_TOL_F32 and e64 < FBANK_TOL
     # ragged: lengths straddling the 64-frame tile and the 160-sample hop; each utterance normalised on its own frames
     lens = [257, 10239, 10240, 10241, 48000, 20479, 66666]
     wavs = synth.ragged_waveforms(lens, seed=9)
@@ -190,10 +202,10 @@ def test_fbank_batch_and_ragged_match_oracle():
     for i, wv in enumerate(wavs):
         want = ref_cpu.logmel_fbank(wv.unsqueeze(0))[0, 0].t()
         assert rows[off[i]:off[i + 1]].shape == want.shape
-        err = (rows[off[i]:off[i + 1]] - want).abs().max().item()
-        worst = max(worst, err)
-        assert err < FBANK_TOL, (lens[i], err)
-    print("fbank batch + ragged: max abs err vs oracle %.2e" % worst)
+        e32 = (rows[off[i]:off[i + 1]] - want).abs().max().item()
+        e64 = (rows[off[i]:off[i + 1]] - _fbank_f64(wv).t()).abs().max().item()
+        print("fbank ragged: %6d samples, max abs err vs f32 oracle %.2e, vs f64 oracle %.2e" % (lens[i], e32, e64))
+        assert e32 < FBANK_TOL_F32 and e64 < FBANK_TOL, (lens[i], e32, e64)
     # bf16 output is the rounded f32 output
     rows16 = fb.rows(torch.cat(wavs).to(DEV), plan, torch.bfloat16).float().cpu()
     assert (rows16 - rows).abs().max() < 0.04
@@ -244,7 +256,8 @@ def test_stage_taps_match_reference_f32(name, golden, meta, supernet):
 
 # bf16 path, stage by stage, against the same reference module outputs.  Every stage reads bf16-rounded inputs (relative
 # rounding 2^-9 = 2e-3 per element) and the error random-walks through ~7 tensors per block, so the bound is on the
-# relative L2 error of the whole activation: 2e-2 (measured on MI355X: printed; 3e-3 at layer1 to ~9e-3 at catconv).
+# relative L2 error of the whole activation: 1.5e-2 = 3x the largest measured value (MI355X, printed: 2e-3 .. 3e-3 at
+# layer1 / first_conv, growing to 4.2e-3 ("smallest") and 5.0e-3 ("odd") at catconv; pooled statistics 1.6e-3).
 # This is the per-stage check of the fast bf16 kernels (tap GEMM layer1, LDS-DMA 1x1 GEMMs, fused Res2 chain, the
 # epilogue SE sums) that the f32 test above cannot give: they only exist in bf16.
 @pytest.mark.parametrize("name", ["smallest", "odd"])
@@ -278,7 +291,7 @@ def test_stage_taps_match_reference_bf16(name, golden, meta, supernet):
     errs["embed"] = ((emb.cpu()[0].double() - want.double()).norm() / want.double().norm()).item()
     print(name, "bf16 rel L2 per stage", {k: "%.2e" % v for k, v in errs.items()})
     for k, v in errs.items():
-        assert v < 2e-2, (k, errs)
+        assert v < 1.5e-2, (k, errs)
 
 
 # ------------------------------------------------------------------------------------------ scoring / l2norm
@@ -296,6 +309,54 @@ def test_cosine_trials_match_calculate_score(golden, meta):
     assert np.array_equal(labels, lab) and pairs[0] == [trials[0]["enroll"], trials[0]["test"]]
     one = sugar_amd.calculate_score(vecs[3].to(DEV), vecs[8].to(DEV), "cosine")
     assert abs(one - ref_cpu.cosine_score(vecs[3], vecs[8])) < 2e-6
+
+
+def test_cosine_trials_full_size_config4_against_reference():
+    """BASELINE config 4 at full size: 4 874 unit vectors, the 37 720-pair list, against the reference's own
+    calculate_score outputs (tests/golden/round2.npz).  Random unit vectors in 192-d give 37 720 scores inside +-0.35, so
+    27 213 neighbouring gaps are below 1e-5 (some pairs are drawn twice: gap 0): "identical ordering" is asserted as (a)
+    identical argsort on the near-tie-free sub-list and (b) no inversion larger than the arithmetic error anywhere.
+    Also times the kernel (trials/s, achieved GB/s over N*192*4 + trials*12 bytes) into gpurun_out/score_full.log."""
+    import os
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = np.load(os.path.join(root, "tests", "golden", "round2.npz"))["score/full"]
+    n_utts, n_trials = 4874, 37720
+    vec = F.normalize(synth.normal("score4/vec", (n_utts, 192), seed=4), p=2, dim=1).to(DEV)
+    lab, a, b = synth.trial_pairs(n_utts, n_trials, seed=4)
+    seg = torch.arange(n_utts + 1, dtype=torch.int32, device=DEV)
+    e = torch.from_numpy(a.astype(np.int32)).to(DEV)
+    t = torch.from_numpy(b.astype(np.int32)).to(DEV)
+    from sugar_amd.scores import score_pairs
+    got = score_pairs(vec, seg, e, t).double().cpu().numpy()
+    err = np.abs(got - want).max()
+    assert err < 2e-6, err
+    order = np.argsort(want, kind="stable")
+    keep = [order[0]]
+    for i in order[1:]:
+        if want[i] - want[keep[-1]] > 1e-5:
+            keep.append(i)
+    keep = np.array(sorted(keep))
+    assert len(keep) > 5000
+    assert np.array_equal(np.argsort(got[keep], kind="stable"), np.argsort(want[keep], kind="stable"))
+    by_gpu = want[np.argsort(got, kind="stable")]                     # reference scores in the GPU's order
+    assert (by_gpu[:-1] - by_gpu[1:]).max() < 4e-6                   # never decreasing by more than twice the error
+    for _ in range(5):
+        score_pairs(vec, seg, e, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        score_pairs(vec, seg, e, t)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 200
+    nbytes = n_utts * 192 * 4 + n_trials * 12
+    line = ("cosine_trials_kernel, %d trials over %d vectors: %.1f us per call (host-paced), %.2e trials/s, %.1f GB/s of "
+            "%d algorithmic bytes; max |score - reference| %.2e" % (n_trials, n_utts, dt * 1e6, n_trials / dt,
+                                                                    nbytes / dt / 1e9, nbytes, err))
+    print(line)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "score_full.log"), "w") as f:
+        f.write(line + "\n")
 
 
 def test_cosine_tiny_norm_uses_eps_per_vector():

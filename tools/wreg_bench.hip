@@ -16,6 +16,12 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
   fputc('\n', stderr);
 }
+int device_cu_count(int* n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SUGAR_EHIP;
+  return hipDeviceGetAttribute(n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess ? SUGAR_OK : SUGAR_EHIP;
+}
+int64_t tune_get(int) { return 0; }
 }  // namespace sugar
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -53,28 +59,57 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&y, (size_t)R * N * 2)); CK(hipMalloc(&yref, (size_t)R * N * 2)); CK(hipMalloc(&flush, 1u << 30));
   CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  // the weights once more in gemm_wreg_kernel<8, 2, 2>'s fragment order (pack_conv, conv_gemm.hip)
+  std::vector<uint16_t> hf(hw.size());
+  {
+    size_t d = 0;
+    for (int slab = 0; slab < N / 256; ++slab)
+      for (int wv = 0; wv < 8; ++wv)
+        for (int c = 0; c < 16; ++c)
+          for (int m = 0; m < 2; ++m)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int co = slab * 256 + wv * 32 + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
+              for (int q = 0; q < 8; ++q) hf[d++] = hw[(size_t)co * 512 + kk + q];
+            }
+  }
+  bf16* wfrag;
+  CK(hipMalloc(&wfrag, hf.size() * 2));
+  CK(hipMemcpy(wfrag, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
   Gemm1x1Args a;
   a.x = x; a.w = w; a.y = yref; a.y2 = nullptr; a.scale = nullptr; a.shift = nullptr;
   a.ldx = K; a.ldw = K; a.ldy = N; a.ldy2 = 0; a.y2_from = 0; a.R = R; a.cout = N; a.K = K; a.flags = EPI_RELU;
   a.n_co_tiles = N / 128;
   launch_variant<128, 128, 2>(a, 0);
-  a.y = y;
-  CK(hipMemset(y, 0, (size_t)R * N * 2));
-  launch_wreg<8, 2, 2>(a, 0);
   CK(hipDeviceSynchronize());
   std::vector<uint16_t> h0((size_t)R * N), h1((size_t)R * N);
   CK(hipMemcpy(h0.data(), yref, h0.size() * 2, hipMemcpyDeviceToHost));
-  CK(hipMemcpy(h1.data(), y, h1.size() * 2, hipMemcpyDeviceToHost));
-  size_t bad = 0;
-  for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
-  printf("WREG_KNOCK=%d  R=%d: wreg vs <128,128,2>: %zu of %zu outputs differ\n", WREG_KNOCK, R, bad, h0.size());
-  const double flop = 2.0 * R * N * K;
-  for (int cold = 0; cold < 2; ++cold) {
-    const float t0 = timeit([&] { launch_variant<128, 128, 2>(a, 0); }, 10, cold ? flush : nullptr);
-    const float t1 = timeit([&] { launch_wreg<8, 2, 1>(a, 0); }, 10, cold ? flush : nullptr);
-    const float t2 = timeit([&] { launch_wreg<8, 2, 2>(a, 0); }, 10, cold ? flush : nullptr);
-    printf("  %s  <128,128,2> %.4f ms %.0f TF   wreg 64-deep stages %.4f ms %.0f TF   wreg 128-deep stages %.4f ms %.0f TF\n", cold ? "cold" : "warm", t0,
-           flop / t0 / 1e9, t1, flop / t1 / 1e9, t2, flop / t2 / 1e9);
+  a.y = y;
+  struct V { const char* name; int (*fn)(const Gemm1x1Args&, hipStream_t); bool frag; };
+  const V vs[] = {{"base", launch_wreg<8, 2, 2, 0, 0>, false}, {"base+wfrag", launch_wreg<8, 2, 2, 0, 0>, true},
+                  {"lag2+wfrag", launch_wreg<8, 2, 2, 2, 0>, true}, {"defer+wfrag", launch_wreg<8, 2, 2, 0, 1>, true},
+                  {"lag2+defer+wfrag", launch_wreg<8, 2, 2, 2, 1>, true}};
+  for (const V& v : vs) {
+    a.wfrag = v.frag ? wfrag : nullptr;
+    CK(hipMemset(y, 0, (size_t)R * N * 2));
+    v.fn(a, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h1.data(), y, h1.size() * 2, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
+    printf("WREG_KNOCK=%d  R=%d  %-18s vs <128,128,2>: %zu of %zu outputs differ\n", WREG_KNOCK, R, v.name, bad, h0.size());
   }
+  const double flop = 2.0 * R * N * K;
+  for (int round = 0; round < 3; ++round)
+    for (int cold = 0; cold < 2; ++cold) {
+      a.wfrag = nullptr;
+      const float t0 = timeit([&] { launch_variant<128, 128, 2>(a, 0); }, 10, cold ? flush : nullptr);
+      printf("  %s  <128,128,2> %.4f ms %.0f TF |", cold ? "cold" : "warm", t0, flop / t0 / 1e9);
+      for (const V& v : vs) {
+        a.wfrag = v.frag ? wfrag : nullptr;
+        const float t = timeit([&] { v.fn(a, 0); }, 10, cold ? flush : nullptr);
+        printf(" %s %.4f |", v.name, t);
+      }
+      printf("\n");
+    }
   return 0;
 }
