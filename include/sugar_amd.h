@@ -128,6 +128,21 @@ int sugar_fbank_fwd(const float* d_wav, const int64_t* d_wav_off, const int32_t*
                     const int32_t* d_row_off, int B, int64_t R, int t_max,
                     float* d_logmel, void* d_feats, int dtype, void* stream);
 
+/* Allocation-free variant of sugar_fbank_fwd.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory or carry a scratch buffer -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same kernels and same results as sugar_fbank_fwd bit for bit; the log-mel scratch that d_logmel
+ * brings in there is a file-scope __device__ array of the library here (5.44 MB per GPU, held until the process ends),
+ * so one call handles at most SUGAR_NOALLOC_MAX_BATCH utterances totalling SUGAR_NOALLOC_MAX_FRAMES frames (163 s of
+ * audio) and larger calls return SUGAR_EINVAL.  The caller still passes inputs and the output.  After the one-off
+ * per-device set-up (done by sugar_subnet_create on that device, otherwise by the first front-end call there) it calls
+ * no hipMalloc / hipFree / allocating routine.  Every call on a GPU shares that GPU's array: calls that overlap on one
+ * GPU (two streams, two threads) race; serialise them.  Nothing in the array has to start at zero. */
+#define SUGAR_NOALLOC_MAX_FRAMES 16384
+#define SUGAR_NOALLOC_MAX_BATCH 256
+int sugar_fbank_fwd_noalloc(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
+                            const int32_t* d_row_off, int B, int64_t R, int t_max, void* d_feats, int dtype,
+                            void* stream);
+
 /* Replaces: DynamicTDNN.forward on a cloned subnet (dynamictdnn.py:645-666) [+ F.normalize(p=2) of
  * sugar/vectors.py:143-144 when `normalize` != 0].
  *   d_feats [R][80] dtype of the subnet;  d_emb float32 [B][embed_dim] */

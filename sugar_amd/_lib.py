@@ -48,6 +48,7 @@ SYMBOLS = {
     "sugar_workspace_bytes": (_i64, [_vp, _i, _i64]),
     "sugar_fbank_scratch_bytes": (_i64, [_i, _i64]),
     "sugar_fbank_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _i, _vp]),
+    "sugar_fbank_fwd_noalloc": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _i, _vp]),
     "sugar_tdnn_fwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _i64, _vp, _i, _vp]),
     "sugar_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _i64, _vp, _i, _vp]),
     "sugar_tdnn_tap": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _vp]),

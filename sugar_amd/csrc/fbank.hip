@@ -42,7 +42,7 @@ struct FbankTables {
   float* mel_w = nullptr;    // [NMEL][MEL_MAXW]
 };
 
-// The tables live in file-scope __device__ arrays: every GPU the
+// The tables and the scratch of the allocation-free entry point live in file-scope __device__ arrays: every GPU the
 // library runs on holds its own copy at its own address, found once per device with hipGetSymbolAddress (in host code
 // the array NAMES are host-side stand-ins, never device addresses) and kept in g_dev.  Nothing here calls hipMalloc.
 __device__ __align__(256) float2 d_tw[NFFT];
@@ -51,9 +51,17 @@ __device__ __align__(256) int d_mel_lo[NMEL];
 __device__ __align__(256) int d_mel_cnt[NMEL];
 __device__ __align__(256) float d_mel_w[NMEL * MEL_MAXW];
 
+// scratch of sugar_fbank_fwd_noalloc: the log-mel rows before normalisation + the chunk statistics of long utterances
+// (what d_logmel brings in for sugar_fbank_fwd), for at most NOALLOC_FRAMES frames in NOALLOC_BATCH utterances: 5.44 MB
+constexpr int NOALLOC_FRAMES = SUGAR_NOALLOC_MAX_FRAMES, NOALLOC_BATCH = SUGAR_NOALLOC_MAX_BATCH;
+constexpr int64_t NOALLOC_FLOATS =
+    (int64_t)NOALLOC_FRAMES * NMEL + (NOALLOC_FRAMES / (8 * 40) + NOALLOC_BATCH + 1) * (2 * NMEL);
+static __device__ __align__(256) float scratch[NOALLOC_FLOATS];
+
 struct DevState {
   bool ready = false;
   FbankTables tb;
+  float* scratch = nullptr;     // device address of `scratch` on this GPU
 };
 constexpr int MAX_DEVICES = 64;
 std::mutex g_mu;
@@ -107,12 +115,15 @@ int get_dev(DevState* out) {
     SUGAR_HIP(hipGetSymbolAddress((void**)&tb.mel_lo, HIP_SYMBOL(d_mel_lo)));
     SUGAR_HIP(hipGetSymbolAddress((void**)&tb.mel_cnt, HIP_SYMBOL(d_mel_cnt)));
     SUGAR_HIP(hipGetSymbolAddress((void**)&tb.mel_w, HIP_SYMBOL(d_mel_w)));
+    float* sc = nullptr;
+    SUGAR_HIP(hipGetSymbolAddress((void**)&sc, HIP_SYMBOL(scratch)));
     SUGAR_HIP(hipMemcpy(tb.tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
     SUGAR_HIP(hipMemcpy(tb.win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
     SUGAR_HIP(hipMemcpy(tb.mel_lo, lo.data(), NMEL * sizeof(int), hipMemcpyHostToDevice));
     SUGAR_HIP(hipMemcpy(tb.mel_cnt, cnt.data(), NMEL * sizeof(int), hipMemcpyHostToDevice));
     SUGAR_HIP(hipMemcpy(tb.mel_w, mw.data(), mw.size() * sizeof(float), hipMemcpyHostToDevice));
     t.tb = tb;
+    t.scratch = sc;
     t.ready = true;
   }
   *out = t;
@@ -351,6 +362,8 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float*
 // M2 = sum M2_c + n_c (mean_c - mean)^2) and normalises its rows.  An utterance of one chunk merges to exactly the
 // numbers of instnorm_kernel, so an utterance's features do not depend on what else is in the batch.
 constexpr int NORM_CHUNK = NORM_LANES * NORM_CACHE;
+static_assert(NOALLOC_FLOATS == (int64_t)NOALLOC_FRAMES * NMEL + (NOALLOC_FRAMES / NORM_CHUNK + NOALLOC_BATCH + 1) * (2 * NMEL),
+              "scratch of the allocation-free entry point = fbank_scratch_floats(NOALLOC_BATCH, NOALLOC_FRAMES)");
 
 __device__ __forceinline__ int norm_slot(const int32_t* row_off, int b) { return row_off[b] / NORM_CHUNK + b; }
 
@@ -483,3 +496,22 @@ int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_
 }
 
 }  // namespace sugar
+
+// Allocation-free variant of sugar_fbank_fwd (include/sugar_amd.h): same kernels, the log-mel scratch is this GPU's
+// copy of the file-scope `scratch` array instead of a caller buffer.  After the one-off per-device set-up (get_dev: done
+// by sugar_subnet_create, else by the first front-end call on the device) it calls no allocating routine.
+extern "C" int sugar_fbank_fwd_noalloc(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
+                                       const int32_t* d_row_off, int B, int64_t R, int t_max, void* d_feats, int dtype,
+                                       void* stream) {
+  using namespace sugar;
+  SUGAR_CHECK_ARG(B > 0 && B <= NOALLOC_BATCH && R > 0 && R <= NOALLOC_FRAMES,
+                  "fbank_fwd_noalloc: %d utterances / %lld frames exceed the static scratch (at most %d utterances, %d "
+                  "frames per call); use sugar_fbank_fwd with a caller buffer",
+                  B, (long long)R, NOALLOC_BATCH, NOALLOC_FRAMES);
+  DevState ds;
+  int rc = get_dev(&ds);
+  if (rc) return rc;
+  SUGAR_CHECK_ARG(fbank_scratch_floats(B, R) <= NOALLOC_FLOATS, "fbank_fwd_noalloc: scratch too small");
+  return launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, ds.scratch, d_feats, dtype, (hipStream_t)stream);
+}
+
