@@ -71,7 +71,6 @@ enum {
   TUNE_GENERIC_RES2,          // != 0: Res2 chain as 7 generic launches
   TUNE_RES2_MAX_T,            // frames one Res2 workgroup holds (0 = the kernel's 384)
   TUNE_GENERIC_LAYER1,        // != 0: layer1 through the generic masked-load conv
-  TUNE_SE_UNFUSED,            // != 0: SE mean as its own pass over y instead of the last_conv epilogue sums
   TUNE_COUNT
 };
 int64_t tune_get(int key);
@@ -169,12 +168,18 @@ struct ConvIO {
 };
 
 int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s);
+// true when launch_conv sends this conv to the LDS-DMA 1x1 GEMMs of conv1x1.hip, which do not read d_rowseg
+bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype);
 
 // Tap conv (dilation 1, bf16) as an LDS-DMA GEMM over overlapping rows of a zero-padded copy of x (conv1x1.hip):
 // d_xpad must hold gemm_taps_pad_rows(L, B, R) rows of L.cin_p elements.
 bool gemm_taps_eligible(const ConvLayer& L, int ldx, int dtype);
 int64_t gemm_taps_pad_rows(const ConvLayer& L, int B, int64_t R);
-int launch_gemm_taps(const ConvLayer& L, const void* d_x, void* d_xpad, void* d_y, int ldy, const int32_t* d_row_off,
+int gemm_taps_slack(const ConvLayer& L, int B, int64_t R);   // rows that close the padded buffer
+int launch_pad_rows(const ConvLayer& L, const void* d_x, void* d_xpad, const int32_t* d_row_off, int B, int64_t R, int t_max,
+                    hipStream_t s);
+int64_t gemm_taps_orow_ints(const ConvLayer& L, int B, int64_t R);   // int32 entries of the output-row map d_orow
+int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, void* d_y, int ldy, const int32_t* d_row_off,
                      int B, int64_t R, int t_max, hipStream_t s);
 
 // Pack a reference-layout conv weight [cout][cin][k] (host f32) into ConvLayer storage with an internal channel
@@ -192,8 +197,11 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
 // ---- front-end (fbank.hip) ----------------------------------------------------------------------
 // d_logmel: fbank_scratch_floats(B, R) floats = [R][80] log-mel rows + the chunk statistics of long utterances
 int64_t fbank_scratch_floats(int B, int64_t R);
+// halo > 0: d_feats is the zero-padded layout of launch_pad_rows (utterance b's frame t at row row_off[b] + 2 halo b +
+// halo + t, halo zero rows either side of every utterance, `slack` more after the last one), written directly
 int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
-                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s);
+                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s, int halo = 0,
+                 int slack = 0);
 
 // ---- SE / pooling / tail (se_pool.hip) ----------------------------------------------------------
 struct SELayer {            // device, f32, transposed for coalesced reads
@@ -208,7 +216,7 @@ struct SELayer {            // device, f32, transposed for coalesced reads
 int64_t se_part_floats(const SELayer& se, int dtype, int B, int64_t R);
 int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, int t_max,
                     float* d_part, float* d_scale, int dtype, hipStream_t s);
-// out = y * scale[b] + S ;  S += out (skipped when d_S_out == nullptr)
+// out = y * scale[b] + S ;  S += out (when write_S)                                    dynamictdnn.py:98-100, :657-660
 int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, void* d_S, int ldS, void* d_out,
                     int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s);
 

@@ -45,6 +45,9 @@ struct Gemm1x1Args {
   const int32_t* row_off = nullptr;
   int B = 0, xmap = 0;
   const bf16* wfrag = nullptr;   // gemm_wreg_kernel: the weights once more, in its fragment-load order (or nullptr)
+  // gemm_wreg_kernel over the PADDED row space of a tap conv (layer1): GEMM row q reads its K vector at x + q * ldx and
+  // stores to output row orow[q] (-1: a row between two utterances, nothing to store).  nullptr: output row = q.
+  const int32_t* orow = nullptr;
 };
 
 constexpr int TK = 64;
@@ -385,7 +388,8 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
 // (slot free for the DMA of stage g + 1 + D) and has its own rows of stage g + 1 in LDS.
 // Same sums in the same order as gemm_tile: bit-identical outputs.
 // Diagnostic builds only (tools/wreg_bench.hip with -DWREG_KNOCK=bits): leave out the MFMAs (1), the LDS fragment reads
-// (2), the activation DMA (4), the output stores (8) or all but one weight-fragment address (16) to see what the kernel's time is made of; wrong results.
+// (2), the activation DMA (4), the output stores (8), all but one weight-fragment address (16), the per-stage workgroup
+// barrier (32) or the counted vmcnt wait (64) to see what the kernel's time is made of; wrong results.
 #ifndef WREG_KNOCK
 #define WREG_KNOCK 0
 #endif
@@ -397,10 +401,18 @@ constexpr int WR_TN = 64, WR_SUB = WR_TN * 128;   // a [64 frames x 64 k] sub-ti
 // the late waves issuing their DMA share after the first MFMA block instead of right behind the barrier: 0.0502 /
 // 0.0610 standalone, no difference in the pipeline (first_conv + last_conv 0.334 ms per step either way).  Kept from
 // that round: the weight fragments pre-packed in load order (a.wfrag): 0.0546 -> 0.0505 warm, 0.0661 -> 0.0628 cold.
-template <int KC, int CM, int SK>   // K = 64 KC; 16 CM channels per wave; SK sub-tiles (64 k each) per stage and barrier
-__global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(Gemm1x1Args a, int n_ftiles, int n_slabs, int P) {
+// K = 64 KC; 16 CM channels per wave; SK sub-tiles (64 k each) per stage and barrier; NW waves = a slab of 16 CM NW channels
+//   <8, 2, 2, 8>   512 -> 512 convs of the SE-Res2 blocks: 256-channel slabs, 128 weight VGPRs
+//   <7, 2, 1, 8>   layer1 (80 mel x 5 taps = K 400 -> 448) over the padded row space, outputs through the row map a.orow
+//   <24, 2, 2, 4>  pooling.linear1 (1536 -> 128, tanh): one 128-channel slab, one wave per SIMD with 384 weight VGPRs
+//                  (8 waves x 16 channels need 256 registers each and spill).  The 128 x 64 tile kernel
+//                  re-streamed the 384 KiB weight panel from L2 for every 64-frame tile (2/3 of its DMA bytes) and ran at
+//                  3.1 TB/s of activations; here only the activations move.
+template <int KC, int CM, int SK, int NW = 16 / CM>
+__global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args a, int n_ftiles, int n_slabs, int P) {
   static_assert(KC % SK == 0, "whole stages per tile");
-  constexpr int NW = 16 / CM, DI = 8 / NW;             // waves; DMA instructions per wave and sub-tile
+  static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
+  constexpr int DI = 8 / NW, SLAB = 16 * CM * NW;      // DMA instructions per wave and sub-tile; channels per workgroup
   constexpr int WR_NS = 12 / SK + 1, WR_D = WR_NS - 1, WR_STAGE = SK * WR_SUB, KS = KC / SK, H = 2 * SK;
   constexpr int EPI_STRIDE = CM * 32 + 16, EPW = WR_TN * EPI_STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -412,13 +424,21 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   const int t0 = (int)((int64_t)p * n_ftiles / P), t1 = (int)((int64_t)(p + 1) * n_ftiles / P);
   if (t0 >= t1) return;
   const int G = (t1 - t0) * KS;                       // stages of this workgroup
-  const int co_w = slab * 256 + wv * (CM * 16);       // first channel of this wave
+  const int co_w = slab * SLAB + wv * (CM * 16);      // first channel of this wave
+
+  // output-row map of the tiles in flight (a.orow): 4 slots of 64 int32 behind the staging, filled by wave 0 with one
+  // 256-byte LDS-DMA per tile, issued with the tile's first stage (so it has landed, and every wave has passed a
+  // barrier behind wave 0's wait for it, long before the tile's epilogue)
+  int32_t* omap = (int32_t*)(smem + WR_NS * WR_STAGE + NW * EPW);
 
   // ---- activation DMA: wave wv fills rows 8 DI wv .. + 8 DI - 1 of a stage ----------------------------------------
   const int drow = wv * (8 * DI) + (lane >> 3);
   auto issue = [&](int g) {                           // stage g of this workgroup -> slot g % WR_NS
     if (WREG_KNOCK & 4) return;
     const int slot = g % WR_NS, tile = t0 + g / KS, ks = g % KS;
+    if (a.orow && ks == 0 && wv == 0)                 // the counted waits below only get stricter by this extra request
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.orow + (size_t)tile * WR_TN + lane),
+                                       (__attribute__((address_space(3))) void*)(omap + ((g / KS) & 3) * WR_TN), 4, 0, 0);
 #pragma unroll
     for (int sub = 0; sub < SK; ++sub)
 #pragma unroll
@@ -474,6 +494,7 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   unsigned char* ep = smem + WR_NS * WR_STAGE + wv * EPW;   // this wave's [64 frames][16 CM channels] staging
+
   auto frags = [&](bf16x8 (&f)[4], int slot, int hh) {   // half hh of the stage: sub-tile hh / 2, 32-deep half hh % 2
     const unsigned char* xb = smem + slot * WR_STAGE + (hh >> 1) * WR_SUB;
     const int h = hh & 1;
@@ -493,6 +514,7 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
       }
   };
   auto epilogue = [&](int t) {   // tile t: lane (fr, fq) of acc[m][n] holds frame 16 n + fr, channels 16 m + 4 fq + {0..3}
+    const int32_t* om = omap + ((t - t0) & 3) * WR_TN;
 #pragma unroll
     for (int m = 0; m < CM; ++m) {
       const f32x4 sc = scp[m], sh = shp[m];
@@ -519,9 +541,10 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
 #pragma unroll
     for (int i = 0; i < WR_TN / RPP; ++i) {
       const int f = i * RPP + lane / LPR, ch = lane % LPR;
-      const int r = t * WR_TN + f, co = co_w + ch * 8;
+      const int q = t * WR_TN + f, co = co_w + ch * 8;
+      const int r = a.orow ? om[f] : q;                      // orow is -1 beyond the last padded row as well
       const u32x4 v = *(const u32x4*)(ep + f * EPI_STRIDE + ch * 16);
-      if (r < a.R && co < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
+      if (q < a.R && r >= 0 && co < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
         *(u32x4*)(a.y + (size_t)r * a.ldy + co) = v;
         if (a.y2 && co >= a.y2_from) *(u32x4*)(a.y2 + (size_t)r * a.ldy2 + co) = v;
       }
@@ -548,9 +571,12 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
       }
       // own rows of stage g + 1 have landed once at most the D - 1 younger stages are outstanding (epilogue stores in
       // the count can only make the wait longer)
-      if (g + WR_D < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * DI * SK) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!(WREG_KNOCK & 64)) {
+        if (g + WR_D < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WR_D - 1) * DI * SK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (WREG_KNOCK & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (g + 1 + WR_D < G) issue(g + 1 + WR_D);       // into the slot stage g was read from
       if (g + 1 < G) frags(fb[0], (g + 1) % WR_NS, 0);
       mfmas(H * ks + H - 1, fb[(H - 1) & 1]);
@@ -560,17 +586,17 @@ __global__ __launch_bounds__(1024 / CM, CM == 4 ? 1 : 2) void gemm_wreg_kernel(G
   }
 }
 
-template <int KC, int CM, int SK>
+template <int KC, int CM, int SK, int NW = 16 / CM>
 int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
-  constexpr int smem = (12 / SK + 1) * SK * WR_SUB + (16 / CM) * WR_TN * (CM * 32 + 16);
+  constexpr int smem = (12 / SK + 1) * SK * WR_SUB + NW * WR_TN * (CM * 32 + 16) + 4 * WR_TN * 4;
   static OptInMask opted{0};
-  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK>, smem, &opted)) return rc;
+  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK, NW>, smem, &opted)) return rc;
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu)) return rc;
-  const int n_slabs = (int)ceil_div(a.cout, 256), n_ftiles = (int)ceil_div(a.R, WR_TN);
+  const int n_slabs = (int)ceil_div(a.cout, 16 * CM * NW), n_ftiles = (int)ceil_div(a.R, WR_TN);
   int P = n_cu / n_slabs / 8 * 8;
   if (P < 8) P = 8;
-  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK>), dim3(n_slabs * P), dim3(1024 / CM), smem, s, a, n_ftiles, n_slabs, P);
+  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK, NW>), dim3(n_slabs * P), dim3(64 * NW), smem, s, a, n_ftiles, n_slabs, P);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
@@ -608,22 +634,63 @@ int64_t gemm_taps_pad_rows(const ConvLayer& L, int B, int64_t R) {
   return R + (int64_t)2 * halo * B + ceil_div(L.k_pad, L.cin_p) + 1;
 }
 
-int launch_gemm_taps(const ConvLayer& L, const void* d_x, void* d_xpad, void* d_y, int ldy, const int32_t* d_row_off,
-                     int B, int64_t R, int t_max, hipStream_t s) {
+int gemm_taps_slack(const ConvLayer& L, int B, int64_t R) {
+  const int halo = (L.ktaps - 1) / 2;
+  return (int)(gemm_taps_pad_rows(L, B, R) - R - (int64_t)2 * halo * B);
+}
+
+// d_xpad <- d_x re-laid with `halo` zero rows before and after every utterance (+ the closing slack rows).  The fused
+// front-end writes that layout itself (launch_fbank with halo > 0) and skips this copy.
+int launch_pad_rows(const ConvLayer& L, const void* d_x, void* d_xpad, const int32_t* d_row_off, int B, int64_t R, int t_max,
+                    hipStream_t s) {
   const int halo = (L.ktaps - 1) / 2, C = L.cin_p;
-  SUGAR_CHECK_ARG(((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_xpad & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && ldy % 8 == 0,
-                  "gemm_taps: unaligned buffers");
-  const int slack = (int)(gemm_taps_pad_rows(L, B, R) - R - (int64_t)2 * halo * B);
+  SUGAR_CHECK_ARG(((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_xpad & 15) == 0, "gemm_taps: unaligned buffers");
+  const int slack = gemm_taps_slack(L, B, R);
   const int64_t items = (int64_t)(t_max + 2 * halo + slack) * (C >> 3);
   const unsigned gx = (unsigned)(ceil_div(items, 256) < 64 ? ceil_div(items, 256) : 64);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, (const bf16*)d_x, C, d_row_off, halo, slack,
                      (bf16*)d_xpad);
   SUGAR_LAUNCH_CHECK();
+  return SUGAR_OK;
+}
+
+// orow[q] = output row of GEMM row q of the padded row space (launch_pad_rows layout: utterance b's frame t is the
+// K vector starting at padded row row_off[b] + 2 halo b + t), or -1 for the 2 halo rows between utterances and for the
+// rows up to the next multiple of 64 behind the last one.
+__global__ __launch_bounds__(256) void build_orow_kernel(const int32_t* __restrict__ row_off, int halo, int n_total,
+                                                         int32_t* __restrict__ orow) {
+  const int b = blockIdx.y, B = gridDim.y;
+  const int s0 = row_off[b], n = row_off[b + 1] - s0;
+  const int q0 = s0 + 2 * halo * b;
+  const int rows = b == B - 1 ? n_total - q0 : n + 2 * halo;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) orow[q0 + i] = i < n ? s0 + i : -1;
+}
+
+int64_t gemm_taps_orow_ints(const ConvLayer& L, int B, int64_t R) {
+  return round_up(R + (int64_t)(L.ktaps - 1) * B, WR_TN);
+}
+
+int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, void* d_y, int ldy, const int32_t* d_row_off,
+                     int B, int64_t R, int t_max, hipStream_t s) {
+  const int halo = (L.ktaps - 1) / 2, C = L.cin_p;
+  SUGAR_CHECK_ARG(((uintptr_t)d_xpad & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && ldy % 8 == 0, "gemm_taps: unaligned buffers");
   Gemm1x1Args a;
   a.x = (const bf16*)d_xpad; a.w = (const bf16*)L.w; a.y = (bf16*)d_y; a.y2 = nullptr;
   a.scale = L.scale; a.shift = L.shift;
   a.ldx = C; a.ldw = L.k_pad; a.ldy = ldy; a.ldy2 = 0; a.y2_from = 0;
   a.R = (int)R; a.cout = L.cout; a.K = L.k_pad; a.flags = L.flags;
+  if (L.wfrag && d_orow && L.k_pad == 448 && L.cout % 256 == 0 && R >= tune_get(TUNE_GEMM_WREG_MIN_R)) {
+    // large inputs: weights in registers, one pass over the padded rows (the tile kernel below re-streams the weight
+    // panel and the activation rows from L2 for each of its 128 x 128 tiles: 554 MB of DMA for 91 MB of tensors)
+    const int64_t n_total = gemm_taps_orow_ints(L, B, R);
+    const unsigned gx = (unsigned)(ceil_div(t_max + 2 * halo + WR_TN, 256) < 8 ? ceil_div(t_max + 2 * halo + WR_TN, 256) : 8);
+    hipLaunchKernelGGL(build_orow_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, d_row_off, halo, (int)n_total, d_orow);
+    SUGAR_LAUNCH_CHECK();
+    a.R = (int)(R + (int64_t)2 * halo * B);           // GEMM rows = padded rows
+    a.orow = d_orow;
+    a.wfrag = (const bf16*)L.wfrag;
+    return launch_wreg<7, 2, 1, 8>(a, s);
+  }
   a.n_co_tiles = (int)ceil_div(L.cout, 128);
   a.row_off = d_row_off; a.B = B; a.xmap = 2 * halo;
   return launch_variant<128, 128, 2>(a, s);
@@ -672,6 +739,14 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
     const bool no_pp = tune_get(TUNE_GEMM_NO_PINGPONG) != 0;       // A/B switch: both waves of a SIMD in step
     if (uniform) return launch_variant<256, 256, 2>(a, s);
     return no_pp ? launch_split<0>(a, s) : launch_split<1>(a, s);
+  }
+  // pooling.linear1 at full width (K = 1536 -> 128 + tanh) on large inputs: weights in registers, only the activations
+  // stream (the tunable gemm_wreg_min_r switches it together with the 512-channel convs)
+  if (L.wfrag && a.K == 1536 && L.cout == 128 && R >= tune_get(TUNE_GEMM_WREG_MIN_R)) {
+    a.wfrag = (const bf16*)L.wfrag;
+    // (walking the frame tiles from the last one down, so that the first reads hit what the catconv launch wrote last
+    // into the Infinity Cache, measured no difference: 70.8 vs 70.9 us in the pipeline)
+    return launch_wreg<24, 2, 2, 4>(a, s);
   }
   a.n_co_tiles = 1;
   return launch_variant<128, 64, 3>(a, s);

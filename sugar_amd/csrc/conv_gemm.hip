@@ -294,20 +294,31 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
   }
   hipError_t e = hipMalloc(&L->w, n * esz);
   if (e == hipSuccess) e = hipMemcpy(L->w, host, n * esz, hipMemcpyHostToDevice);
-  if (e == hipSuccess && dtype == SUGAR_BF16 && k == 1 && cin_p == 512 && L->k_pad == 512 && L->n_pad % 256 == 0) {
-    // gemm_wreg_kernel<8, 2, 2> (conv1x1.hip): wave wv of channel slab `slab` loads fragment (c, m) as one contiguous
-    // KiB: lane fq * 16 + fr holds W[slab * 256 + wv * 32 + m * 16 + fr][c * 32 + fq * 8 .. + 7]
+  // gemm_wreg_kernel<KC, CM, SK, NW> (conv1x1.hip) wants the weights once more in its fragment-load order: wave wv of
+  // channel slab `slab` loads fragment (c, m) as one contiguous KiB, lane fq * 16 + fr holding
+  // W[slab * 16 CM NW + wv * 16 CM + m * 16 + fr][c * 32 + fq * 8 .. + 7].  Shapes that kernel serves:
+  //   K = 512, 256-channel slabs (CM 2, NW 8): first / last convs of the blocks;  K = 1536 -> 128 (CM 2, NW 4): pooling.linear1;
+  //   K = 448 (80 mel x 5 taps, padded), 256-channel slabs (CM 2, NW 8): layer1 as a GEMM over overlapping rows
+  int f_cm = 0, f_nw = 8;
+  if (dtype == SUGAR_BF16 && k == 1 && L->k_pad == cin_p) {
+    if (cin_p == 512 && L->n_pad % 256 == 0) f_cm = 2;
+    else if (cin_p == 1536 && cout_p == 128 && L->n_pad == 128) f_cm = 2, f_nw = 4;
+  } else if (dtype == SUGAR_BF16 && dil == 1 && L->k_pad == 448 && L->n_pad % 256 == 0) {
+    f_cm = 2;
+  }
+  if (e == hipSuccess && f_cm) {
     uint16_t* frag = (uint16_t*)malloc(n * 2);
     if (!frag) { free(host); set_error("pack_conv: host alloc"); return SUGAR_ENOMEM; }
     const uint16_t* src = (const uint16_t*)host;
+    const int slab_ch = 16 * f_cm * f_nw, kc2 = L->k_pad / 32;
     size_t d = 0;
-    for (int slab = 0; slab < L->n_pad / 256; ++slab)
-      for (int wv = 0; wv < 8; ++wv)
-        for (int c = 0; c < 16; ++c)
-          for (int m = 0; m < 2; ++m)
+    for (int slab = 0; slab < L->n_pad / slab_ch; ++slab)
+      for (int wv = 0; wv < f_nw; ++wv)
+        for (int c = 0; c < kc2; ++c)
+          for (int m = 0; m < f_cm; ++m)
             for (int lane = 0; lane < 64; ++lane) {
-              const int co = slab * 256 + wv * 32 + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
-              for (int q = 0; q < 8; ++q) frag[d++] = src[(size_t)co * 512 + kk + q];
+              const int co = slab * slab_ch + wv * 16 * f_cm + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
+              for (int q = 0; q < 8; ++q) frag[d++] = src[(size_t)co * L->k_pad + kk + q];
             }
     e = hipMalloc(&L->wfrag, n * 2);
     if (e == hipSuccess) e = hipMemcpy(L->wfrag, frag, n * 2, hipMemcpyHostToDevice);

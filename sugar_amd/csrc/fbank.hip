@@ -130,6 +130,8 @@ int get_dev(DevState* out) {
   return SUGAR_OK;
 }
 
+__device__ __forceinline__ int PX(int i) { return i + (i >> 4); }   // padded index into a wave's FFT exchange buffer
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -152,7 +154,10 @@ __global__ __launch_bounds__(256, 4) void fbank_fft_kernel(const float* __restri
   __shared__ __attribute__((aligned(16))) float samples[SPAN];
   // per wave ONE 2 KB exchange buffer: every pass reads its 4 inputs into registers before it writes, and a
   // wavefront's LDS instructions execute in program order, so passes run in place; |X|^2 reuses the same bytes
-  __shared__ __attribute__((aligned(16))) float2 fbuf[4][NBIN];
+  // (entry i of the exchange buffer sits at i + i / 16: with plain indexing the scattered writes of passes 0-2 put up
+  // to 16 lanes on one bank pair -- 34 % of the kernel's LDS cycles were bank conflicts; with one pad slot per 16 entries
+  // every pass reads and writes 4 lanes per bank pair, the minimum for 64 lanes x 8 bytes)
+  __shared__ __attribute__((aligned(16))) float2 fbuf[4][NBIN + NBIN / 16];
   __shared__ float tile[FRAMES * SLD];
 
   const int b = blockIdx.y;
@@ -230,39 +235,38 @@ __global__ __launch_bounds__(256, 4) void fbank_fft_kernel(const float* __restri
       v2 = make_float2(s2.x * wn[2].x, s2.y * wn[2].y);
       v3 = make_float2(s3.x * wn[3].x, s3.y * wn[3].y);
       fft4(v0, v1, v2, v3);
-      float2* o = A + 4 * j;
-      o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+      A[PX(4 * j)] = v0; A[PX(4 * j + 1)] = v1; A[PX(4 * j + 2)] = v2; A[PX(4 * j + 3)] = v3;
     }
     __builtin_amdgcn_wave_barrier();
     // pass 1 (Ns = 4)
     {
-      v0 = A[j]; v1 = cmul(A[j + 64], tw1[0]); v2 = cmul(A[j + 128], tw1[1]); v3 = cmul(A[j + 192], tw1[2]);
+      v0 = A[PX(j)]; v1 = cmul(A[PX(j + 64)], tw1[0]); v2 = cmul(A[PX(j + 128)], tw1[1]); v3 = cmul(A[PX(j + 192)], tw1[2]);
       fft4(v0, v1, v2, v3);
-      float2* o = Bf + ((j >> 2) << 4) + (j & 3);
-      o[0] = v0; o[4] = v1; o[8] = v2; o[12] = v3;
+      const int o = ((j >> 2) << 4) + (j & 3);
+      Bf[PX(o)] = v0; Bf[PX(o + 4)] = v1; Bf[PX(o + 8)] = v2; Bf[PX(o + 12)] = v3;
     }
     __builtin_amdgcn_wave_barrier();
     // pass 2 (Ns = 16)
     {
-      v0 = Bf[j]; v1 = cmul(Bf[j + 64], tw2[0]); v2 = cmul(Bf[j + 128], tw2[1]); v3 = cmul(Bf[j + 192], tw2[2]);
+      v0 = Bf[PX(j)]; v1 = cmul(Bf[PX(j + 64)], tw2[0]); v2 = cmul(Bf[PX(j + 128)], tw2[1]); v3 = cmul(Bf[PX(j + 192)], tw2[2]);
       fft4(v0, v1, v2, v3);
-      float2* o = A + ((j >> 4) << 6) + (j & 15);
-      o[0] = v0; o[16] = v1; o[32] = v2; o[48] = v3;
+      const int o = ((j >> 4) << 6) + (j & 15);
+      A[PX(o)] = v0; A[PX(o + 16)] = v1; A[PX(o + 32)] = v2; A[PX(o + 48)] = v3;
     }
     __builtin_amdgcn_wave_barrier();
     // pass 3 (Ns = 64): natural-order Z[0..255] lands in Bf
     {
-      v0 = A[j]; v1 = cmul(A[j + 64], tw3[0]); v2 = cmul(A[j + 128], tw3[1]); v3 = cmul(A[j + 192], tw3[2]);
+      v0 = A[PX(j)]; v1 = cmul(A[PX(j + 64)], tw3[0]); v2 = cmul(A[PX(j + 128)], tw3[1]); v3 = cmul(A[PX(j + 192)], tw3[2]);
       fft4(v0, v1, v2, v3);
-      Bf[j] = v0; Bf[j + 64] = v1; Bf[j + 128] = v2; Bf[j + 192] = v3;
+      Bf[PX(j)] = v0; Bf[PX(j + 64)] = v1; Bf[PX(j + 128)] = v2; Bf[PX(j + 192)] = v3;
     }
     __builtin_amdgcn_wave_barrier();
     // real-FFT split: E = (Z[k] + conj Z[256-k]) / 2, O = -i (Z[k] - conj Z[256-k]) / 2, X = E + W512^k O
     float2 zks[4], zms[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      zks[t] = Bf[j + 64 * t];
-      zms[t] = Bf[(NBIN - j - 64 * t) & (NBIN - 1)];
+      zks[t] = Bf[PX(j + 64 * t)];
+      zms[t] = Bf[PX((NBIN - j - 64 * t) & (NBIN - 1))];
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256, 4) void fbank_fft_kernel(const float* __restri
       float s = 0.f, s2 = 0.f;                           // taps past a filter's end have zero weight
 #pragma unroll
       for (int i = 0; i < MEL_MAXW; ++i) {
-        // lo + i may run up to 18 floats past bin 255: still inside this wave's 512-float buffer (finite leftovers of
+        // lo + i may run up to 18 floats past bin 255: still inside this wave's 544-float buffer (finite leftovers of
         // pass 3), and those taps have zero weight
         s = fmaf(pw[lo0 + i], mw0[i], s);
         s2 = fmaf(pw[lo1 + i], mw1[i], s2);
@@ -300,10 +304,27 @@ __global__ __launch_bounds__(256, 4) void fbank_fft_kernel(const float* __restri
 constexpr int NORM_LANES = 8;   // row lanes per mel bin
 constexpr int NORM_CACHE = 40;  // rows per lane kept in registers
 
+// Output rows: utterance b's frame t at row row_off[b] + t, or -- halo > 0, the layout the layer1 tap GEMM reads
+// (conv1x1.hip, launch_pad_rows) -- at row_off[b] + 2 halo b + halo + t with the halo rows (and, behind the last
+// utterance, `slack` more rows) zeroed here.
+template <typename T>
+__device__ __forceinline__ T* padded_rows(T* feats, int s, int n, int b, int n_utts, int halo, int slack, bool first_part,
+                                          bool last_part) {
+  if (!halo) return feats + (size_t)s * NMEL;
+  T* base = feats + ((size_t)s + (size_t)2 * halo * b + halo) * NMEL;
+  if (first_part)
+    for (int i = threadIdx.x; i < halo * NMEL; i += blockDim.x) (base - halo * NMEL)[i] = from_f32<T>(0.f);
+  if (last_part) {
+    const int after = (halo + (b == n_utts - 1 ? slack : 0)) * NMEL;
+    for (int i = threadIdx.x; i < after; i += blockDim.x) (base + (size_t)n * NMEL)[i] = from_f32<T>(0.f);
+  }
+  return base;
+}
+
 template <typename T>
 __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float* __restrict__ logmel,
                                                                      const int32_t* __restrict__ row_off,
-                                                                     T* __restrict__ feats) {
+                                                                     T* __restrict__ feats, int halo, int slack) {
   __shared__ float red[NORM_LANES][NMEL];
   const int b = blockIdx.x;
   const int s = row_off[b], n = row_off[b + 1] - s;
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float*
   for (int i = 0; i < NORM_LANES; ++i) var += red[i][m];
   var /= (float)n;                                     // biased, as InstanceNorm1d
   const float inv = 1.0f / sqrtf(var + 1e-5f);
-  T* __restrict__ dst = feats + (size_t)s * NMEL + m;
+  T* __restrict__ dst = padded_rows(feats, s, n, b, (int)gridDim.x, halo, slack, true, true) + m;
 #pragma unroll
   for (int i = 0; i < NORM_CACHE; ++i) {
     const int r = rl + NORM_LANES * i;
@@ -413,7 +434,7 @@ template <typename T>
 __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_apply_kernel(const float* __restrict__ logmel,
                                                                            const int32_t* __restrict__ row_off,
                                                                            const float* __restrict__ part,
-                                                                           T* __restrict__ feats) {
+                                                                           T* __restrict__ feats, int halo, int slack) {
   const int b = blockIdx.y, c = blockIdx.x;
   const int s = row_off[b], nu = row_off[b + 1] - s;
   const int r0 = c * NORM_CHUNK;
@@ -443,7 +464,8 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_apply_kernel(const 
     var = (float)(m2 / (double)nu);                    // biased, as InstanceNorm1d
   }
   const float inv = 1.0f / sqrtf(var + 1e-5f);
-  T* __restrict__ dst = feats + (size_t)(s + r0) * NMEL + m;
+  T* __restrict__ dst = padded_rows(feats, s, nu, b, (int)gridDim.y, halo, slack, c == 0, r0 + NORM_CHUNK >= nu) +
+                        (size_t)r0 * NMEL + m;
 #pragma unroll
   for (int i = 0; i < NORM_CACHE; ++i) {
     const int r = rl + NORM_LANES * i;
@@ -460,7 +482,7 @@ int fbank_init() {
 int64_t fbank_scratch_floats(int B, int64_t R) { return R * NMEL + (R / NORM_CHUNK + B + 1) * (2 * NMEL); }
 
 int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
-                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s) {
+                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s, int halo, int slack) {
   SUGAR_CHECK_ARG(d_wav && d_wav_off && d_wav_len && d_row_off && d_logmel && d_feats, "fbank: null pointer");
   SUGAR_CHECK_ARG(B > 0 && B <= 65535 && t_max > 0 && R >= t_max, "fbank: bad batch %d / t_max %d / R %lld", B, t_max, (long long)R);
   SUGAR_CHECK_ARG(dtype == SUGAR_F32 || dtype == SUGAR_BF16, "fbank: bad dtype %d", dtype);
@@ -478,19 +500,19 @@ int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_
     SUGAR_LAUNCH_CHECK();
     if (dtype == SUGAR_F32)
       hipLaunchKernelGGL(instnorm_apply_kernel<float>, grid, dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off, part,
-                         (float*)d_feats);
+                         (float*)d_feats, halo, slack);
     else
       hipLaunchKernelGGL(instnorm_apply_kernel<bf16>, grid, dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off, part,
-                         (bf16*)d_feats);
+                         (bf16*)d_feats, halo, slack);
     SUGAR_LAUNCH_CHECK();
     return SUGAR_OK;
   }
   if (dtype == SUGAR_F32)
     hipLaunchKernelGGL(instnorm_kernel<float>, dim3((unsigned)B), dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off,
-                       (float*)d_feats);
+                       (float*)d_feats, halo, slack);
   else
     hipLaunchKernelGGL(instnorm_kernel<bf16>, dim3((unsigned)B), dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off,
-                       (bf16*)d_feats);
+                       (bf16*)d_feats, halo, slack);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }

@@ -73,8 +73,8 @@ struct Prof {
 
 // ---- tunables: environment read once, then atomics ----
 static const char* kTuneNames[TUNE_COUNT] = {"gemm_wreg_min_r", "gemm_uniform", "gemm_no_pingpong", "generic_res2",
-                                             "res2_max_t", "generic_layer1", "se_unfused"};
-static const int64_t kTuneDefaults[TUNE_COUNT] = {43008, 0, 0, 0, 0, 0, 0};
+                                             "res2_max_t", "generic_layer1"};
+static const int64_t kTuneDefaults[TUNE_COUNT] = {43008, 0, 0, 0, 0, 0};
 static std::atomic<int64_t> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -334,6 +334,7 @@ struct Workspace {
   int2* rowseg;
   float* logmel;
   void *feats, *featp, *S, *cat, *mid1, *mid2, *ybuf, *hbuf, *abuf;
+  int32_t* orow;     // layer1 tap GEMM: output-row map of the padded row space
   float *separt, *sescale, *pooled, *poolpart, *tailpart;
   double* bnpart;    // recalibration: partial sums, batch (scale, shift), pre-BN embeddings
   float *bnscale, *bnshift, *embpre;
@@ -353,6 +354,7 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   w.logmel = (float*)take(fbank_scratch_floats(B, R) * 4);
   w.feats = take(R * SUGAR_N_MELS * esz);
   w.featp = take(gemm_taps_pad_rows(n->layer1, B, R) * n->in_feats * esz);   // zero-padded copy for the layer1 GEMM
+  w.orow = (int32_t*)take(gemm_taps_orow_ints(n->layer1, B, R) * 4);
   w.S = take(R * n->c0p * esz);
   w.cat = take(R * (int64_t)n->depth * n->c0p * esz);
   w.mid1 = take(R * n->midp_max * esz);
@@ -375,6 +377,12 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
 }
 
 // ---------------------------------------------------------------------------------- forward
+// Does layer1 run as the tap GEMM over the zero-padded feature copy (w.featp)?
+static bool layer1_as_tap_gemm(const SugarSubnet* n) {
+  return !tune_get(TUNE_GENERIC_LAYER1) && gemm_taps_eligible(n->layer1, n->in_feats, n->dtype);
+}
+
+// feats == nullptr: the front-end has already written the padded copy w.featp (sugar_embed_fwd)
 static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* row_off, int B, int64_t R, int t_max,
                         const Workspace& w, float* d_emb, int normalize, int tap, float* tap_out, hipStream_t s) {
   const int dt = n->dtype;
@@ -385,17 +393,29 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     if (tap != id || !tap_out) return SUGAR_OK;
     return launch_to_f32(p, ld, R, C, tap_out, dt, s);
   };
-  { Prof p(SUGAR_STAGE_ROWSEG, s); if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc; }
+  // The per-row (start, end) table is what the generic masked-load conv reads; the LDS-DMA GEMMs and the fused Res2
+  // chain do not.  It is built at the first launch that needs it: the bf16 path of a full-width subnet never does.
+  bool rowseg_built = false;
+  auto conv = [&](const ConvLayer& L, const ConvIO& cio) -> int {
+    if (!rowseg_built && !gemm1x1_eligible(L, cio, dt)) {
+      Prof p(SUGAR_STAGE_ROWSEG, s);
+      if (int rc2 = launch_build_rowseg(row_off, B, t_max, w.rowseg, s)) return rc2;
+      rowseg_built = true;
+    }
+    return launch_conv(L, cio, w.rowseg, R, dt, s);
+  };
 
   ConvIO io;
   io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
   {
     Prof p(SUGAR_STAGE_LAYER1, s);
-    const bool generic_l1 = tune_get(TUNE_GENERIC_LAYER1) != 0;                 // A/B switch for the parity tests
-    if (!generic_l1 && gemm_taps_eligible(n->layer1, n->in_feats, dt))
-      rc = launch_gemm_taps(n->layer1, feats, w.featp, w.S, n->c0p, row_off, B, R, t_max, s);
-    else
-      rc = launch_conv(n->layer1, io, w.rowseg, R, dt, s);
+    if (layer1_as_tap_gemm(n)) {
+      if (feats && (rc = launch_pad_rows(n->layer1, feats, w.featp, row_off, B, R, t_max, s))) return rc;
+      rc = launch_gemm_taps(n->layer1, w.featp, w.orow, w.S, n->c0p, row_off, B, R, t_max, s);
+    } else {
+      SUGAR_CHECK_ARG(feats, "forward: features missing");
+      rc = conv(n->layer1, io);
+    }
     if (rc) return rc;
   }
   if ((rc = tapcopy(0, w.S, n->c0p, n->c0p))) return rc;
@@ -409,7 +429,7 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     ConvIO f;
     f.x = xin; f.ldx = ldin; f.y = w.mid1; f.ldy = b.midp;
     f.y2 = w.mid2; f.ldy2 = b.midp; f.y2_from = (SUGAR_RES2_SCALE - 1) * b.wp;   // 8th split passes through (:300-301)
-    { Prof p(SUGAR_STAGE_FIRST, s); if ((rc = launch_conv(b.first, f, w.rowseg, R, dt, s))) return rc; }
+    { Prof p(SUGAR_STAGE_FIRST, s); if ((rc = conv(b.first, f))) return rc; }
     if ((rc = tapcopy(1 + 4 * i, w.mid1, b.midp, b.midp))) return rc;
     {
     Prof p(SUGAR_STAGE_RES2, s);
@@ -421,13 +441,13 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
       r.x = col(w.mid1, (int64_t)j * b.wp); r.ldx = b.midp;
       if (j > 0) { r.x2 = col(w.mid2, (int64_t)(j - 1) * b.wp); r.ldx2 = b.midp; }
       r.y = col(w.mid2, (int64_t)j * b.wp); r.ldy = b.midp;
-      if ((rc = launch_conv(b.res[j], r, w.rowseg, R, dt, s))) return rc;
+      if ((rc = conv(b.res[j], r))) return rc;
     }
     }
     if ((rc = tapcopy(2 + 4 * i, w.mid2, b.midp, b.midp))) return rc;
     ConvIO l;
     l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
-    { Prof p(SUGAR_STAGE_LAST, s); if ((rc = launch_conv(b.last, l, w.rowseg, R, dt, s))) return rc; }
+    { Prof p(SUGAR_STAGE_LAST, s); if ((rc = conv(b.last, l))) return rc; }
     if ((rc = tapcopy(3 + 4 * i, w.ybuf, n->c0p, n->c0p))) return rc;
     { Prof p(SUGAR_STAGE_SE_SCALE, s); if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.separt, w.sescale, dt, s))) return rc; }
     void* out = col(w.cat, (int64_t)i * n->c0p);
@@ -441,11 +461,11 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
   }
   ConvIO c;
   c.x = w.cat; c.ldx = ldcat; c.y = w.hbuf; c.ldy = n->ccatp;
-  { Prof p(SUGAR_STAGE_CATCONV, s); if ((rc = launch_conv(n->catconv, c, w.rowseg, R, dt, s))) return rc; }
+  { Prof p(SUGAR_STAGE_CATCONV, s); if ((rc = conv(n->catconv, c))) return rc; }
   if ((rc = tapcopy(100, w.hbuf, n->ccatp, n->ccatp))) return rc;
   ConvIO p1;
   p1.x = w.hbuf; p1.ldx = n->ccatp; p1.y = w.abuf; p1.ldy = n->bott;
-  { Prof p(SUGAR_STAGE_POOL1, s); if ((rc = launch_conv(n->pool1, p1, w.rowseg, R, dt, s))) return rc; }
+  { Prof p(SUGAR_STAGE_POOL1, s); if ((rc = conv(n->pool1, p1))) return rc; }
   if ((rc = tapcopy(102, w.abuf, n->bott, n->bott))) return rc;
   { Prof p(SUGAR_STAGE_POOL_STATS, s); if ((rc = launch_pool_stats(n->pool, w.abuf, n->bott, w.hbuf, n->ccatp, row_off, B, t_max, w.pooled, w.poolpart, dt, s))) return rc; }
   if (tap == 101 && tap_out)
@@ -656,8 +676,16 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
   SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
   hipStream_t s = (hipStream_t)stream;
-  { Prof p(SUGAR_STAGE_FBANK, s); if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, w.logmel, w.feats, net->dtype, s))) return rc; }
-  return tdnn_forward(net, w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
+  // the front-end writes its features straight into the zero-padded layout the layer1 tap GEMM reads (no copy kernel)
+  const bool padded = layer1_as_tap_gemm(net);
+  const int halo = padded ? (net->layer1.ktaps - 1) / 2 : 0;
+  {
+    Prof p(SUGAR_STAGE_FBANK, s);
+    if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, w.logmel, padded ? w.featp : w.feats,
+                           net->dtype, s, halo, padded ? gemm_taps_slack(net->layer1, B, R) : 0)))
+      return rc;
+  }
+  return tdnn_forward(net, padded ? nullptr : w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
 }
 
 int sugar_tdnn_recalibrate(SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R, int t_max,
@@ -774,19 +802,23 @@ int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, i
   if (rc) { free_conv(&L); return rc; }
   int2* rowseg = nullptr;
   void* xpad = nullptr;
+  int32_t* orow = nullptr;
   hipStream_t s = (hipStream_t)stream;
   // same dispatch as the forward (tdnn_forward): dilation-1 tap convs that qualify run as the LDS-DMA GEMM over
   // overlapping rows (layer1), everything else through launch_conv
   const bool taps = !d_x2 && !tune_get(TUNE_GENERIC_LAYER1) && gemm_taps_eligible(L, cin, dtype);
   if (hipMalloc(&rowseg, R * sizeof(int2)) != hipSuccess ||
-      (taps && hipMalloc(&xpad, (size_t)gemm_taps_pad_rows(L, B, R) * cin * 2) != hipSuccess)) {
+      (taps && (hipMalloc(&xpad, (size_t)gemm_taps_pad_rows(L, B, R) * cin * 2) != hipSuccess ||
+                hipMalloc(&orow, (size_t)gemm_taps_orow_ints(L, B, R) * 4) != hipSuccess))) {
     if (rowseg) (void)hipFree(rowseg);
+    if (xpad) (void)hipFree(xpad);
     free_conv(&L);
     set_error("conv1d: hipMalloc");
     return SUGAR_EHIP;
   }
   if (taps) {
-    rc = launch_gemm_taps(L, d_x, xpad, d_y, cout, d_row_off, B, R, t_max, s);
+    rc = launch_pad_rows(L, d_x, xpad, d_row_off, B, R, t_max, s);
+    if (!rc) rc = launch_gemm_taps(L, xpad, orow, d_y, cout, d_row_off, B, R, t_max, s);
   } else {
     rc = launch_build_rowseg(d_row_off, B, t_max, rowseg, s);
     if (!rc) {
@@ -798,6 +830,7 @@ int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, i
   (void)hipStreamSynchronize(s);
   (void)hipFree(rowseg);
   if (xpad) (void)hipFree(xpad);
+  if (orow) (void)hipFree(orow);
   free_conv(&L);
   return rc;
 }

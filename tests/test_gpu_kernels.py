@@ -117,6 +117,18 @@ def test_conv512_weights_in_registers_is_bit_identical_to_tiles(case):
     assert _rel(wreg, want) < 6e-3
 
 
+@pytest.mark.parametrize("frames", [[129], [301] * 40, [1500] * 9 + [7]], ids=["129", "40x301", "ragged"])
+def test_pool1_weights_in_registers_is_bit_identical_to_tiles(frames):
+    """pooling.linear1 (1536 -> 128, tanh) switches to gemm_wreg_kernel<24, 2, 2, 4> with the 512-channel convs."""
+    case = (1536, 128, 1, 1, 4, frames)
+    with _lib.tuned(gemm_wreg_min_r=0):
+        wreg, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=8)
+    with _lib.tuned(gemm_wreg_min_r=1 << 40):
+        tiles, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=8)
+    assert torch.equal(wreg, tiles)
+    assert _rel(wreg, want) < 6e-3
+
+
 def test_wide_gemm_schedules_are_bit_identical():
     """catconv shape with full 256 x 256 rounds: ping-pong + split tail (what the forward runs) == in-step == uniform grid."""
     case = (1536, 1536, 1, 1, 1, [301] * 40)
@@ -129,17 +141,23 @@ def test_wide_gemm_schedules_are_bit_identical():
     assert _rel(pp, want) < 6e-3
 
 
-@pytest.mark.parametrize("frames", [[63], [301, 17, 130, 63, 2, 1]], ids=["one", "ragged"])
+@pytest.mark.parametrize("frames", [[63], [301, 17, 130, 63, 2, 1], [301] * 20 + [64, 1, 65]], ids=["one", "ragged", "20x301"])
 def test_layer1_tap_gemm_and_generic_conv_agree_with_oracle(frames):
-    """layer1 (80 -> 512, k 5) runs as an LDS-DMA GEMM over overlapping zero-padded rows; the generic masked-load conv is
-    the other implementation of the same sums.  Both against F.conv1d, and against each other."""
+    """layer1 (80 -> 512, k 5) runs as an LDS-DMA GEMM over overlapping zero-padded rows -- 128 x 128 tiles with a
+    per-row utterance search for small inputs, the weights-in-registers kernel over the padded row space with an
+    output-row map for large ones; the generic masked-load conv is a third implementation of the same sums.  All three
+    against F.conv1d; the two GEMM forms sum in the same order and must agree bit for bit."""
     case = (80, 512, 5, 1, 3, frames)
-    gemm, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=7)
+    with _lib.tuned(gemm_wreg_min_r=1 << 40):
+        tiles, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=7)
+    with _lib.tuned(gemm_wreg_min_r=0):
+        wreg, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=7)
     with _lib.tuned(generic_layer1=1):
         generic, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=7)
-    assert _rel(gemm, want) < 6e-3 and _rel(generic, want) < 6e-3
+    assert _rel(tiles, want) < 6e-3 and _rel(generic, want) < 6e-3
+    assert torch.isfinite(wreg).all() and torch.equal(wreg, tiles)
     # same products, different summation order (k-tile order vs tap order): only f32 reassociation + one bf16 ulp
-    assert _rel(gemm, generic) < 4e-3
+    assert _rel(tiles, generic) < 4e-3
 
 
 def test_conv_rejects_bad_arguments():

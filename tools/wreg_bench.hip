@@ -46,8 +46,9 @@ float timeit(F f, int iters, void* flush) {
   return tot / iters;
 }
 
-int main(int argc, char** argv) {
-  const int R = argc > 1 ? atoi(argv[1]) : 77056, N = 512, K = 512;
+template <int KC, int CM, int NW>
+int run(int R) {
+  const int N = 16 * CM * NW * (KC == 8 ? 2 : 1), K = 64 * KC;
   std::vector<uint16_t> hx((size_t)R * K), hw((size_t)N * K);
   uint32_t s = 12345;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return host_f32_to_bf16(((s >> 8) & 0xffff) / 32768.0f - 1.0f); };
@@ -59,17 +60,18 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&y, (size_t)R * N * 2)); CK(hipMalloc(&yref, (size_t)R * N * 2)); CK(hipMalloc(&flush, 1u << 30));
   CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
-  // the weights once more in gemm_wreg_kernel<8, 2, 2>'s fragment order (pack_conv, conv_gemm.hip)
+  // the weights once more in the kernel's fragment order (pack_conv, conv_gemm.hip)
   std::vector<uint16_t> hf(hw.size());
   {
     size_t d = 0;
-    for (int slab = 0; slab < N / 256; ++slab)
-      for (int wv = 0; wv < 8; ++wv)
-        for (int c = 0; c < 16; ++c)
-          for (int m = 0; m < 2; ++m)
+    const int slab_ch = 16 * CM * NW;
+    for (int slab = 0; slab < N / slab_ch; ++slab)
+      for (int wv = 0; wv < NW; ++wv)
+        for (int c = 0; c < 2 * KC; ++c)
+          for (int m = 0; m < CM; ++m)
             for (int lane = 0; lane < 64; ++lane) {
-              const int co = slab * 256 + wv * 32 + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
-              for (int q = 0; q < 8; ++q) hf[d++] = hw[(size_t)co * 512 + kk + q];
+              const int co = slab * slab_ch + wv * 16 * CM + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
+              for (int q = 0; q < 8; ++q) hf[d++] = hw[(size_t)co * K + kk + q];
             }
   }
   bf16* wfrag;
@@ -78,38 +80,44 @@ int main(int argc, char** argv) {
   Gemm1x1Args a;
   a.x = x; a.w = w; a.y = yref; a.y2 = nullptr; a.scale = nullptr; a.shift = nullptr;
   a.ldx = K; a.ldw = K; a.ldy = N; a.ldy2 = 0; a.y2_from = 0; a.R = R; a.cout = N; a.K = K; a.flags = EPI_RELU;
-  a.n_co_tiles = N / 128;
-  launch_variant<128, 128, 2>(a, 0);
+  auto tiles = [&](const Gemm1x1Args& aa, hipStream_t st) {
+    Gemm1x1Args b = aa;
+    if (KC == 8) { b.n_co_tiles = N / 128; return launch_variant<128, 128, 2>(b, st); }
+    b.n_co_tiles = 1;
+    return launch_variant<128, 64, 3>(b, st);
+  };
+  tiles(a, 0);
   CK(hipDeviceSynchronize());
   std::vector<uint16_t> h0((size_t)R * N), h1((size_t)R * N);
   CK(hipMemcpy(h0.data(), yref, h0.size() * 2, hipMemcpyDeviceToHost));
   a.y = y;
-  struct V { const char* name; int (*fn)(const Gemm1x1Args&, hipStream_t); bool frag; };
-  const V vs[] = {{"base", launch_wreg<8, 2, 2, 0, 0>, false}, {"base+wfrag", launch_wreg<8, 2, 2, 0, 0>, true},
-                  {"lag2+wfrag", launch_wreg<8, 2, 2, 2, 0>, true}, {"defer+wfrag", launch_wreg<8, 2, 2, 0, 1>, true},
-                  {"lag2+defer+wfrag", launch_wreg<8, 2, 2, 2, 1>, true}};
+  a.wfrag = wfrag;
+  struct V { const char* name; int (*fn)(const Gemm1x1Args&, hipStream_t); };
+  const V vs[] = {{"SK1", launch_wreg<KC, CM, 1, NW>}, {"SK2", launch_wreg<KC, CM, 2, NW>}, {"SK4", launch_wreg<KC, CM, 4, NW>}};
   for (const V& v : vs) {
-    a.wfrag = v.frag ? wfrag : nullptr;
     CK(hipMemset(y, 0, (size_t)R * N * 2));
     v.fn(a, 0);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h1.data(), y, h1.size() * 2, hipMemcpyDeviceToHost));
     size_t bad = 0;
     for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
-    printf("WREG_KNOCK=%d  R=%d  %-18s vs <128,128,2>: %zu of %zu outputs differ\n", WREG_KNOCK, R, v.name, bad, h0.size());
+    printf("K=%d N=%d R=%d  %-6s vs tile kernel: %zu of %zu outputs differ\n", K, N, R, v.name, bad, h0.size());
   }
-  const double flop = 2.0 * R * N * K;
+  const double flop = 2.0 * R * N * K, bytes = 2.0 * R * (K + N);
   for (int round = 0; round < 3; ++round)
     for (int cold = 0; cold < 2; ++cold) {
-      a.wfrag = nullptr;
-      const float t0 = timeit([&] { launch_variant<128, 128, 2>(a, 0); }, 10, cold ? flush : nullptr);
-      printf("  %s  <128,128,2> %.4f ms %.0f TF |", cold ? "cold" : "warm", t0, flop / t0 / 1e9);
+      const float t0 = timeit([&] { tiles(a, 0); }, 10, cold ? flush : nullptr);
+      printf("  %s  tiles %.4f ms %.0f TF %.2f TB/s |", cold ? "cold" : "warm", t0, flop / t0 / 1e9, bytes / t0 / 1e9);
       for (const V& v : vs) {
-        a.wfrag = v.frag ? wfrag : nullptr;
         const float t = timeit([&] { v.fn(a, 0); }, 10, cold ? flush : nullptr);
-        printf(" %s %.4f |", v.name, t);
+        printf(" %s %.4f (%.2f TB/s) |", v.name, t, bytes / t / 1e9);
       }
       printf("\n");
     }
   return 0;
+}
+
+int main(int argc, char** argv) {
+  const int R = argc > 1 ? atoi(argv[1]) : 77056, K = argc > 2 ? atoi(argv[2]) : 512;
+  return K == 512 ? run<8, 2, 8>(R) : run<24, 2, 4>(R);
 }
