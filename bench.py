@@ -2,7 +2,7 @@
 """
 bench.py -- speaker embeddings/sec (3 s @ 16 kHz) of the MI355X-native EfficientTDNN extraction path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload base256|largest256] [--precision bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload base256|largest256|wide256] [--precision bf16|fp32]
 
 One step = one pass of the hot path (waveforms already resident in HBM -> fused fbank -> TDNN -> L2-normalised
 embeddings) over one batch of 256 synthetic 3 s utterances per GPU.  N > 1: launched by torch.distributed.run, one
@@ -28,22 +28,28 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 WORKLOADS = {
-    # name: (config, per-GPU batch, samples)   BASELINE.json configs[1] / configs[2]
-    "base256": ("BASE", 256, 48000),
-    "largest256": ("LARGEST", 256, 48000),
+    # name: (config, per-GPU batch, samples, supernet)   BASELINE.json configs[1] / configs[2]; wide256 = the full
+    # 1024-channel tdnn16m4g (sugar/models/dynamictdnn.py:942-944), the "1024-channel convs" of north_star
+    "base256": ("BASE", 256, 48000, "tdnn8m2g"),
+    "largest256": ("LARGEST", 256, 48000, "tdnn8m2g"),
+    "wide256": ((3, [1024] * 4, [5] * 4, 1536), 256, 48000, "tdnn16m4g"),
 }
+SUPERNETS = {"tdnn8m2g": (80, 192, 4, 512, 5, 1536), "tdnn16m4g": (80, 192, 3, 1024, 5, 1536)}   # supernet_shapes arguments
+PREHEAT_STEPS = 30   # untimed passes at set-up, before the W warm-up steps: the clocks of an idle MI355X take ~25 ms of
+                     # work to ramp, longer than W = 5 steps (measured: 1.351 ms/step timed after 5 steps from idle,
+                     # 1.324 after 60, 1.328 over 100 timed steps); reported in config.preheat_steps
 PEAK = {"bf16": (2500.0, "dense bf16 MFMA peak, MI355X_MICROARCH.md chip table"),
         "fp32": (157.3, "f32 matrix peak, MI355X_MICROARCH.md chip table")}
 
 
-def cpu_baseline(config, seconds=10.0):
+def cpu_baseline(config, shapes, seconds=10.0):
     """Oracle on the host cores: embeddings/s of 8 x 3 s batches (bounded sample of the same workload)."""
     from oracle import ref_cpu
     from sugar_amd import layout, synth
     cores = min(os.cpu_count() or 1, 16)           # the GPU box gives one job a 16-CPU share
     torch.set_num_threads(cores)
-    sd = synth.fill_state_dict(layout.supernet_shapes(), seed=0)
-    osd = ref_cpu.clone_state(sd, config)
+    sd = synth.fill_state_dict(layout.supernet_shapes(*shapes), seed=0)
+    osd = ref_cpu.clone_state(sd, config, num_blocks=shapes[2], channels=shapes[3])
     wav = synth.waveforms(8, 48000, seed=100)
     for _ in range(2):
         ref_cpu.embed(osd, config[0], wav, norm=True)
@@ -104,6 +110,8 @@ def main():
                     help="HIP streams the timed steps alternate over (each with its own workspace).  1 (default) keeps "
                          "the per-kernel roofline clean; the 2-stream rate (consecutive batches overlapping on the GPU) "
                          "is measured after the timed region and reported as 'pipelined'")
+    ap.add_argument("--preheat", type=int, default=PREHEAT_STEPS,
+                    help="untimed set-up passes before the warm-up steps (clock ramp); 0 for counter-collection runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the 2-stream leg after the timed region (rocprofv3 runs: its overlapped kernels would "
@@ -129,10 +137,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg_name, B, L = WORKLOADS[args.workload]
-    config = getattr(layout, cfg_name)
-    sup = sugar_amd.tdnn8m2g()
-    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    cfg, B, L, family = WORKLOADS[args.workload]
+    config = getattr(layout, cfg) if isinstance(cfg, str) else cfg
+    sup = getattr(sugar_amd, family)()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(*SUPERNETS[family]), seed=0))
     sub = sup.clone(config).set_precision(args.precision)
     model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
 
@@ -161,6 +169,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    for i in range(args.preheat):                      # set-up: clock ramp (see PREHEAT_STEPS); no collective
+        model(wav, normalize=True)
+    sync_all()
     for i in range(args.warmup):
         h = step(i)
         if h is not None:
@@ -244,11 +255,16 @@ def main():
         flops_launch = 2.0 * (depth * ch[0]) * ccat * R               # algorithmic: 2 * K * N * frames
         peak, peak_src = PEAK[args.precision]
         achieved = flops_launch / (ms_cat / n_cat * 1e-3) / 1e12 if n_cat else None
-        traffic = None
+        # HBM bytes per launch come from a separate rocprofv3 --pmc job (counters cannot be read from inside this
+        # process; tools/pmc_table.py pivots their CSVs): profiles/traffic_catconv.json; traffic_source says which run that was
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic_catconv.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("%s_%s" % (args.workload, args.precision))
+                tj = json.load(f)
+            traffic = tj.get("%s_%s" % (args.workload, args.precision))
+            traffic_src = "offline: rocprofv3 --pmc passes of this command, %s (profiles/traffic_catconv.json)" \
+                          % tj.get("_source", "round 1")
         out = {
             "metric": "speaker embeddings/sec (3 s @16 kHz)",
             "value": round(world * B * args.steps / dt, 1),
@@ -262,14 +278,15 @@ def main():
                                    % (args.workload, layout.config_name(config), B),
                        "per_gpu_batch": B, "global_batch": world * B, "frames_per_utt": T,
                        "parallelism": "utterance-sharded x%d, all-gather of embeddings" % world,
-                       "streams": len(lanes),
+                       "streams": len(lanes), "preheat_steps": args.preheat,
                        "weights": "deterministic synthetic (sugar_amd/synth.py)"},
             "roofline": {"kernel": "%s catconv launch [%d frames x K %d -> %d]"
                                    % ("gemm1x1_split_kernel<2> (256x256x64 LDS-DMA MFMA GEMM, split-tail grid)" if args.precision == "bf16"
                                       else "conv_gemm_kernel<float,128,128>", R, depth * ch[0], ccat),
                          "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None,
-                         "traffic": traffic, "launches_timed": n_cat,
+                         "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
+                         "launches_timed": n_cat,
                          "avg_launch_ms": round(ms_cat / n_cat, 4) if n_cat else None,
                          "flops_per_launch": flops_launch, "peak_source": peak_src},
         }
@@ -279,7 +296,7 @@ def main():
         if pipelined:
             out["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(config)
+            out["cpu_baseline"] = cpu_baseline(config, SUPERNETS[family])
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

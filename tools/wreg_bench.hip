@@ -119,5 +119,6 @@ int run(int R) {
 
 int main(int argc, char** argv) {
   const int R = argc > 1 ? atoi(argv[1]) : 77056, K = argc > 2 ? atoi(argv[2]) : 512;
-  return K == 512 ? run<8, 2, 8>(R) : run<24, 2, 4>(R);
+  if (K == 512) { run<8, 2, 8>(R); printf("-- one wave per SIMD, 64 channels per wave --\n"); return run<8, 4, 4>(R); }
+  return run<24, 2, 4>(R);
 }
