@@ -16,6 +16,8 @@
 // leaves its online-softmax state (max, sum p, sum p h, sum p h^2) in a table and pool_merge_kernel folds the
 // segments of an utterance in order.  The segment length is fixed, so an utterance's statistics do not depend on
 // what else is in the batch; utterances of one segment are finished by the main kernel as before.
+#include <type_traits>
+
 #include "common.h"
 
 namespace sugar {
@@ -113,16 +115,22 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
   auto store_tile = [&](int buf, int t0) {
     unsigned char* ab = smem + buf * (A_BYTES + H_BYTES);
     unsigned char* hb = ab + A_BYTES;
+    const bool full = t0 + PT <= n && c_base + PC <= ccat_p;      // (uniform) no row or channel of the tile to zero
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
-      *(u32x4*)(ab + row * (A_CH * 16) + ((ch ^ (row & 15)) << 4)) = t0 + row < n ? areg[i] : (u32x4){0u, 0u, 0u, 0u};
+      *(u32x4*)(ab + row * (A_CH * 16) + ((ch ^ (row & 15)) << 4)) = full || t0 + row < n ? areg[i] : (u32x4){0u, 0u, 0u, 0u};
     }
+    if (full) {
 #pragma unroll
-    for (int i = 0; i < H_PER; ++i) {
-      const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
-      const bool ok = t0 + row < n && c_base + ch * E < ccat_p;
-      *(u32x4*)(hb + idx * 16) = ok ? hreg[i] : (u32x4){0u, 0u, 0u, 0u};          // plain [row][channel] image
+      for (int i = 0; i < H_PER; ++i) *(u32x4*)(hb + (tid + i * 512) * 16) = hreg[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < H_PER; ++i) {
+        const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
+        const bool ok = t0 + row < n && c_base + ch * E < ccat_p;
+        *(u32x4*)(hb + idx * 16) = ok ? hreg[i] : (u32x4){0u, 0u, 0u, 0u};        // plain [row][channel] image
+      }
     }
   };
 
@@ -147,36 +155,46 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
       const Frag af = *(const Frag*)(ab + fr * (A_CH * 16) + ((ch ^ (fr & 15)) << 4));
       PoolMma<T>::mma(acc, af, wf[g]);
     }
-    float hv[16];
-    float tmax = -1e30f;
+    // online softmax over this tile's 16 frames of the lane's channel, in the exp2 domain (v_exp_f32 is 2^x): m is the
+    // running maximum of logit * log2(e).  Only the utterance's last tile can hold frames past n: the row masks are
+    // compiled into that tile's copy of the body alone (the loop was VALU-issue-bound: ~300 VALU per tile and wave,
+    // a third of them row tests, selects and LDS address arithmetic).
+    const T* hl = hs + (4 * fh) * PC + wv * 32 + fr;    // frame e of this lane: hl[((e & 3) + 8 * (e >> 2)) * PC]
+    auto body = [&](auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      constexpr float LOG2E = 1.4426950408889634f;
+      float tmax = -1e30f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
-      const bool ok = t0 + row < n;
-      hv[e] = to_f32(hs[row * PC + wv * 32 + fr]);      // zero-filled past n / ccat_p
-      acc[e] = ok ? acc[e] : -1e30f;
-      tmax = fmaxf(tmax, acc[e]);
-    }
-    if (tmax > m) {
-      const float f = __expf(m - tmax);
-      l *= f; s1 *= f; s2 *= f;
-      m = tmax;
-    }
+      for (int e = 0; e < 16; ++e) {
+        if (LAST) acc[e] = t0 + (e & 3) + 8 * (e >> 2) + 4 * fh < n ? acc[e] : -1e30f;
+        tmax = fmaxf(tmax, acc[e]);
+      }
+      tmax *= LOG2E;
+      if (tmax > m) {
+        const float f = __builtin_amdgcn_exp2f(m - tmax);
+        l *= f; s1 *= f; s2 *= f;
+        m = tmax;
+      }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float p = acc[e] > -1e29f ? __expf(acc[e] - m) : 0.f;
-      l += p;
-      const float ph = p * hv[e];
-      s1 += ph;
-      s2 = fmaf(ph, hv[e], s2);
-    }
+      for (int e = 0; e < 16; ++e) {
+        const float hv = to_f32(hl[((e & 3) + 8 * (e >> 2)) * PC]);      // zero-filled past n / ccat_p
+        float p = __builtin_amdgcn_exp2f(fmaf(acc[e], LOG2E, -m));
+        if (LAST) p = acc[e] > -1e29f ? p : 0.f;
+        l += p;
+        const float ph = p * hv;
+        s1 += ph;
+        s2 = fmaf(ph, hv, s2);
+      }
+    };
+    if (t0 + PT <= n) body(std::false_type{});
+    else body(std::true_type{});
     if (more) store_tile((it + 1) & 1, t0 + PT);
     __syncthreads();
   }
   // merge the two half-waves (same channel, disjoint frames)
   const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), s12 = __shfl_xor(s1, 32), s22 = __shfl_xor(s2, 32);
-  const float M = fmaxf(m, m2);
-  const float f1 = __expf(m - M), f2 = __expf(m2 - M);
+  const float M = fmaxf(m, m2);                    // (maxima in the exp2 domain: logit * log2(e))
+  const float f1 = __builtin_amdgcn_exp2f(m - M), f2 = __builtin_amdgcn_exp2f(m2 - M);
   l = l * f1 + l2 * f2;
   s1 = s1 * f1 + s12 * f2;
   s2 = s2 * f1 + s22 * f2;
@@ -205,8 +223,8 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
   float m = p[0], l = p[ccat_p], s1 = p[2 * ccat_p], s2 = p[3 * ccat_p];
   for (int k = 1; k < nseg; ++k) {
     const float* q = p + (size_t)k * 4 * ccat_p;
-    const float m2 = q[0], M = fmaxf(m, m2);
-    const float f1 = __expf(m - M), f2 = __expf(m2 - M);
+    const float m2 = q[0], M = fmaxf(m, m2);       // (exp2 domain, as pool_stats_kernel leaves them)
+    const float f1 = __builtin_amdgcn_exp2f(m - M), f2 = __builtin_amdgcn_exp2f(m2 - M);
     l = l * f1 + q[ccat_p] * f2;
     s1 = s1 * f1 + q[2 * ccat_p] * f2;
     s2 = s2 * f1 + q[3 * ccat_p] * f2;

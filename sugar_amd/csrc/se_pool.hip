@@ -232,7 +232,9 @@ constexpr int TAIL_K = 128;   // pooled features per k-split (24 splits at 3072 
 __global__ __launch_bounds__(256) void tail_partial_kernel(const float* __restrict__ wt, int in_p, int embed,
                                                            const float* __restrict__ pooled, int B,
                                                            float* __restrict__ partial) {
-  __shared__ float ps[TAIL_U][TAIL_K];
+  // pooled tile as [feature][utterance]: the 16 utterances of one feature are four 16-byte broadcast reads (as
+  // [utterance][feature] the loop issued 16 scalar LDS reads per weight and was LDS-issue-bound: 20 us)
+  __shared__ __attribute__((aligned(16))) float ps[TAIL_K][TAIL_U];
   __shared__ float red[4][TAIL_U][64];
   const int tid = threadIdx.x, ol = tid & 63, kl = tid >> 6;
   const int o = blockIdx.y * 64 + ol;
@@ -241,18 +243,23 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(const float* __restri
   const int kn = min(TAIL_K, in_p - k0);
   for (int idx = tid; idx < TAIL_U * TAIL_K; idx += 256) {
     const int u = idx / TAIL_K, i = idx - u * TAIL_K;
-    ps[u][i] = (b0 + u < B && i < kn) ? pooled[(size_t)(b0 + u) * in_p + k0 + i] : 0.f;
+    ps[i][u] = (b0 + u < B && i < kn) ? pooled[(size_t)(b0 + u) * in_p + k0 + i] : 0.f;
   }
   __syncthreads();
   float acc[TAIL_U];
 #pragma unroll
   for (int u = 0; u < TAIL_U; ++u) acc[u] = 0.f;
   const bool o_ok = o < embed;
+  const float* wcol = wt + (size_t)k0 * embed + (o_ok ? o : 0);
 #pragma unroll 8
   for (int i = kl; i < kn; i += 4) {
-    const float w = o_ok ? wt[(size_t)(k0 + i) * embed + o] : 0.f;
+    const float w = o_ok ? wcol[(size_t)i * embed] : 0.f;
 #pragma unroll
-    for (int u = 0; u < TAIL_U; ++u) acc[u] = fmaf(w, ps[u][i], acc[u]);
+    for (int u4 = 0; u4 < TAIL_U / 4; ++u4) {
+      const f32x4 pv = *(const f32x4*)&ps[i][4 * u4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * u4 + e] = fmaf(w, pv[e], acc[4 * u4 + e]);
+    }
   }
 #pragma unroll
   for (int u = 0; u < TAIL_U; ++u) red[kl][u][ol] = acc[u];
