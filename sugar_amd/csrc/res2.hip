@@ -66,6 +66,10 @@ __device__ __forceinline__ u32x4 add_bf16x8(u32x4 xa, u32x4 xb) {
   return __builtin_bit_cast(u32x4, r);
 }
 
+// Round 2, measured and dropped: more waves per utterance.  With B = 256 utterances on 256 CUs the kernel runs ONE
+// workgroup of 8 waves per CU (234 VGPRs), 3 frame tiles per wave; 12 waves x 2 tiles (168 VGPRs, 13 spilled) gave
+// bit-identical outputs but 0.186 ms per step against 0.131 (more fragment reads of the shared weight panel per MFMA,
+// 12-wave barriers), and cutting 301-frame utterances into two time segments for two workgroups per CU 0.205 ms.
 // WREG = 16-byte weight chunks each thread stages per step: 3 (k_pad <= 192) or 5 (k_pad <= 320)
 template <int MT, int R2_TPW, int WREG>
 __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
