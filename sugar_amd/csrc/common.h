@@ -171,6 +171,11 @@ int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int6
 // true when launch_conv sends this conv to the LDS-DMA 1x1 GEMMs of conv1x1.hip, which do not read d_rowseg
 bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype);
 
+// gemm_wreg_kernel with two MFMA tiles per wave (CM = 2): row i of tile m is output channel 8 (i / 4) + 4 m + i % 4 of
+// the wave's 32, so that lane (fr, fq), which holds rows 4 fq .. 4 fq + 3 of both tiles, owns channels 8 fq .. 8 fq + 7
+// of its frames: one 16-byte store per frame straight from the accumulators, no transposition through LDS.
+__host__ __device__ inline int wreg_row(int m, int i) { return 8 * (i >> 2) + 4 * m + (i & 3); }
+
 // Tap conv (dilation 1, bf16) as an LDS-DMA GEMM over overlapping rows of a zero-padded copy of x (conv1x1.hip):
 // d_xpad must hold gemm_taps_pad_rows(L, B, R) rows of L.cin_p elements.
 bool gemm_taps_eligible(const ConvLayer& L, int ldx, int dtype);

@@ -402,19 +402,25 @@ constexpr int WR_TN = 64, WR_SUB = WR_TN * 128;   // a [64 frames x 64 k] sub-ti
 // 0.0610 standalone, no difference in the pipeline (first_conv + last_conv 0.334 ms per step either way).  Kept from
 // that round: the weight fragments pre-packed in load order (a.wfrag): 0.0546 -> 0.0505 warm, 0.0661 -> 0.0628 cold.
 // K = 64 KC; 16 CM channels per wave; SK sub-tiles (64 k each) per stage and barrier; NW waves = a slab of 16 CM NW channels
-//   <8, 2, 2, 8>   512 -> 512 convs of the SE-Res2 blocks: 256-channel slabs, 128 weight VGPRs
-//   <7, 2, 1, 8>   layer1 (80 mel x 5 taps = K 400 -> 448) over the padded row space, outputs through the row map a.orow
-//   <24, 2, 2, 4>  pooling.linear1 (1536 -> 128, tanh): one 128-channel slab, one wave per SIMD with 384 weight VGPRs
+//   <8, 2, 4, 8>   512 -> 512 convs of the SE-Res2 blocks: 256-channel slabs, 128 weight VGPRs; 256-deep stages (two
+//                  barriers per tile; 0.0467-0.0495 ms warm against 0.0496-0.0529 for 128-deep, 0.060 against 0.0634 cold)
+//   <7, 2, 7, 8>   layer1 (80 mel x 5 taps = K 400 -> 448) over the padded row space, outputs through the row map a.orow;
+//                  one stage = one tile (one barrier per tile: 45 us against 55 with 64-deep stages)
+//   <24, 2, 4, 4, STAGED>  pooling.linear1 (1536 -> 128, tanh): one 128-channel slab, one wave per SIMD with 384 weight VGPRs
 //                  (8 waves x 16 channels need 256 registers each and spill).  The 128 x 64 tile kernel
 //                  re-streamed the 384 KiB weight panel from L2 for every 64-frame tile (2/3 of its DMA bytes) and ran at
 //                  3.1 TB/s of activations; here only the activations move.
-template <int KC, int CM, int SK, int NW = 16 / CM>
+// STAGED: the epilogue re-orders a wave's [64 frames x 32 channels] through LDS so that 4 consecutive lanes store one
+// frame's 64 contiguous bytes.  Straight from the accumulators consecutive lanes are consecutive FRAMES (16-byte
+// pieces at the row pitch, four times the write requests); with two waves per SIMD that costs nothing measurable and
+// frees 40 KiB of LDS for deeper stages (K = 512: SK 2 -> 4, layer1: SK 1 -> 7), a lone wave per SIMD
+// (pooling.linear1) stalls on it: 74.5 vs 69 us, so that instantiation keeps the staging.
+template <int KC, int CM, int SK, int NW = 16 / CM, bool STAGED = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args a, int n_ftiles, int n_slabs, int P) {
   static_assert(KC % SK == 0, "whole stages per tile");
   static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
   constexpr int DI = 8 / NW, SLAB = 16 * CM * NW;      // DMA instructions per wave and sub-tile; channels per workgroup
   constexpr int WR_NS = 12 / SK + 1, WR_D = WR_NS - 1, WR_STAGE = SK * WR_SUB, KS = KC / SK, H = 2 * SK;
-  constexpr int EPI_STRIDE = CM * 32 + 16, EPW = WR_TN * EPI_STRIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -426,9 +432,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   const int G = (t1 - t0) * KS;                       // stages of this workgroup
   const int co_w = slab * SLAB + wv * (CM * 16);      // first channel of this wave
 
-  // output-row map of the tiles in flight (a.orow): 4 slots of 64 int32 behind the staging, filled by wave 0 with one
+  // output-row map of the tiles in flight (a.orow): 4 slots of 64 int32 behind the ring, filled by wave 0 with one
   // 256-byte LDS-DMA per tile, issued with the tile's first stage (so it has landed, and every wave has passed a
   // barrier behind wave 0's wait for it, long before the tile's epilogue)
+  constexpr int EPI_STRIDE = CM * 32 + 16, EPW = STAGED ? WR_TN * EPI_STRIDE : 0;
   int32_t* omap = (int32_t*)(smem + WR_NS * WR_STAGE + NW * EPW);
 
   // ---- activation DMA: wave wv fills rows 8 DI wv .. + 8 DI - 1 of a stage ----------------------------------------
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
     for (int c = 0; c < 2 * KC; ++c)
 #pragma unroll
       for (int m = 0; m < CM; ++m)
-        wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + m * 16 + fr) * a.ldw + ((WREG_KNOCK & 16) ? 0 : c * 32) + fq * 8);
+        wf[c][m] = *(const bf16x8*)(a.w + (size_t)(co_w + wreg_row(m, fr)) * a.ldw + ((WREG_KNOCK & 16) ? 0 : c * 32) + fq * 8);
   }
   const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
   // folded-BN vectors of this lane's channels, fetched once: a global load inside the tile loop would be younger than
@@ -481,9 +488,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   for (int m = 0; m < CM; ++m) {
     scp[m] = (f32x4){1.f, 1.f, 1.f, 1.f};
     shp[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (affine) {
-      scp[m] = *(const f32x4*)(a.scale + co_w + m * 16 + 4 * fq);
-      shp[m] = *(const f32x4*)(a.shift + co_w + m * 16 + 4 * fq);
+    if (affine) {                                   // channels wreg_row(m, 4 fq .. 4 fq + 3)
+      scp[m] = *(const f32x4*)(a.scale + co_w + 8 * fq + 4 * m);
+      shp[m] = *(const f32x4*)(a.shift + co_w + 8 * fq + 4 * m);
     }
   }
 
@@ -493,7 +500,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  unsigned char* ep = smem + WR_NS * WR_STAGE + wv * EPW;   // this wave's [64 frames][16 CM channels] staging
 
   auto frags = [&](bf16x8 (&f)[4], int slot, int hh) {   // half hh of the stage: sub-tile hh / 2, 32-deep half hh % 2
     const unsigned char* xb = smem + slot * WR_STAGE + (hh >> 1) * WR_SUB;
@@ -513,44 +519,63 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
         else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][m], f[n], acc[m][n], 0, 0, 0);
       }
   };
-  auto epilogue = [&](int t) {   // tile t: lane (fr, fq) of acc[m][n] holds frame 16 n + fr, channels 16 m + 4 fq + {0..3}
+  // tile t: lane (fr, fq) of acc[m][n] holds frame 16 n + fr, rows 4 fq .. 4 fq + 3 of MFMA tile m = (CM = 2, wreg_row)
+  // channels 8 fq .. 8 fq + 7 of the wave's 32 over m = 0, 1: ReLU -> folded BN -> bf16 and ONE 16-byte store per frame,
+  // 64 contiguous bytes per frame and wave (what the transposition through LDS used to build, without the LDS trip)
+  static_assert(CM == 2, "the direct epilogue pairs two MFMA tiles per wave");
+  unsigned char* ep = smem + WR_NS * WR_STAGE + wv * EPW;   // STAGED: this wave's [64 frames][32 channels] staging
+  auto epilogue = [&](int t) {
     const int32_t* om = omap + ((t - t0) & 3) * WR_TN;
+    const int co = co_w + 8 * fq;
 #pragma unroll
-    for (int m = 0; m < CM; ++m) {
-      const f32x4 sc = scp[m], sh = shp[m];
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 o;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int m = 0; m < CM; ++m) {
         f32x4 v = acc[m][n];
         acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        v = v * sc + sh;
+        v = v * scp[m] + shp[m];
         if (tanh_) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
         }
-        const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4*)(ep + (n * 16 + fr) * EPI_STRIDE + (m * 16 + 4 * fq) * 2) = o;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    constexpr int LPR = CM * 2, RPP = 64 / LPR;              // 16-byte lanes per staged row, rows per pass
 #pragma unroll
-    for (int i = 0; i < WR_TN / RPP; ++i) {
-      const int f = i * RPP + lane / LPR, ch = lane % LPR;
-      const int q = t * WR_TN + f, co = co_w + ch * 8;
+        for (int e = 0; e < 4; ++e) o[4 * m + e] = (bf16)v[e];
+      }
+      if (STAGED) {
+        *(bf16x8*)(ep + (n * 16 + fr) * EPI_STRIDE + 16 * fq) = o;
+        continue;
+      }
+      const int f = n * 16 + fr, q = t * WR_TN + f;
       const int r = a.orow ? om[f] : q;                      // orow is -1 beyond the last padded row as well
-      const u32x4 v = *(const u32x4*)(ep + f * EPI_STRIDE + ch * 16);
+      const u32x4 v = __builtin_bit_cast(u32x4, o);
       if (q < a.R && r >= 0 && co < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
         *(u32x4*)(a.y + (size_t)r * a.ldy + co) = v;
         if (a.y2 && co >= a.y2_from) *(u32x4*)(a.y2 + (size_t)r * a.ldy2 + co) = v;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    if (STAGED) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int LPR = CM * 2, RPP = 64 / LPR;            // 16-byte lanes per staged row, rows per pass
+#pragma unroll
+      for (int i = 0; i < WR_TN / RPP; ++i) {
+        const int f = i * RPP + lane / LPR, ch = lane % LPR;
+        const int q = t * WR_TN + f, cs = co_w + ch * 8;
+        const int r = a.orow ? om[f] : q;
+        const u32x4 v = *(const u32x4*)(ep + f * EPI_STRIDE + ch * 16);
+        if (q < a.R && r >= 0 && cs < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
+          *(u32x4*)(a.y + (size_t)r * a.ldy + cs) = v;
+          if (a.y2 && cs >= a.y2_from) *(u32x4*)(a.y2 + (size_t)r * a.ldy2 + cs) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
   };
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // once: weights and the first D stages
@@ -586,17 +611,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   }
 }
 
-template <int KC, int CM, int SK, int NW = 16 / CM>
+template <int KC, int CM, int SK, int NW = 16 / CM, bool STAGED = false>
 int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
-  constexpr int smem = (12 / SK + 1) * SK * WR_SUB + NW * WR_TN * (CM * 32 + 16) + 4 * WR_TN * 4;
+  // the ring + (STAGED) the waves' output staging + the output-row map slots
+  constexpr int smem = (12 / SK + 1) * SK * WR_SUB + (STAGED ? NW * WR_TN * (CM * 32 + 16) : 0) + 4 * WR_TN * 4;
   static OptInMask opted{0};
-  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK, NW>, smem, &opted)) return rc;
+  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK, NW, STAGED>, smem, &opted)) return rc;
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu)) return rc;
   const int n_slabs = (int)ceil_div(a.cout, 16 * CM * NW), n_ftiles = (int)ceil_div(a.R, WR_TN);
   int P = n_cu / n_slabs / 8 * 8;
   if (P < 8) P = 8;
-  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK, NW>), dim3(n_slabs * P), dim3(64 * NW), smem, s, a, n_ftiles, n_slabs, P);
+  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK, NW, STAGED>), dim3(n_slabs * P), dim3(64 * NW), smem, s, a, n_ftiles, n_slabs, P);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
@@ -689,7 +715,7 @@ int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, vo
     a.R = (int)(R + (int64_t)2 * halo * B);           // GEMM rows = padded rows
     a.orow = d_orow;
     a.wfrag = (const bf16*)L.wfrag;
-    return launch_wreg<7, 2, 1, 8>(a, s);
+    return launch_wreg<7, 2, 7, 8>(a, s);
   }
   a.n_co_tiles = (int)ceil_div(L.cout, 128);
   a.row_off = d_row_off; a.B = B; a.xmap = 2 * halo;
@@ -729,7 +755,7 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // per subnet, so the narrower convs stay on the tile kernel)
       if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) {
         a.wfrag = (const bf16*)L.wfrag;
-        return launch_wreg<8, 2, 2>(a, s);
+        return launch_wreg<8, 2, 4>(a, s);
       }
       a.n_co_tiles = (int)ceil_div(L.cout, 128);
       return launch_variant<128, 128, 2>(a, s);
@@ -746,7 +772,7 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
     a.wfrag = (const bf16*)L.wfrag;
     // (walking the frame tiles from the last one down, so that the first reads hit what the catconv launch wrote last
     // into the Infinity Cache, measured no difference: 70.8 vs 70.9 us in the pipeline)
-    return launch_wreg<24, 2, 2, 4>(a, s);
+    return launch_wreg<24, 2, 4, 4, true>(a, s);
   }
   a.n_co_tiles = 1;
   return launch_variant<128, 64, 3>(a, s);

@@ -296,7 +296,8 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
   if (e == hipSuccess) e = hipMemcpy(L->w, host, n * esz, hipMemcpyHostToDevice);
   // gemm_wreg_kernel<KC, CM, SK, NW> (conv1x1.hip) wants the weights once more in its fragment-load order: wave wv of
   // channel slab `slab` loads fragment (c, m) as one contiguous KiB, lane fq * 16 + fr holding
-  // W[slab * 16 CM NW + wv * 16 CM + m * 16 + fr][c * 32 + fq * 8 .. + 7].  Shapes that kernel serves:
+  // W[slab * 16 CM NW + wv * 16 CM + wreg_row(m, fr)][c * 32 + fq * 8 .. + 7] (CM = 2; wreg_row interleaves the two MFMA
+  // tiles of a wave so that a lane's 8 accumulators of a frame are 8 consecutive channels).  Shapes that kernel serves:
   //   K = 512, 256-channel slabs (CM 2, NW 8): first / last convs of the blocks;  K = 1536 -> 128 (CM 2, NW 4): pooling.linear1;
   //   K = 448 (80 mel x 5 taps, padded), 256-channel slabs (CM 2, NW 8): layer1 as a GEMM over overlapping rows
   int f_cm = 0, f_nw = 8;
@@ -317,7 +318,7 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
         for (int c = 0; c < kc2; ++c)
           for (int m = 0; m < f_cm; ++m)
             for (int lane = 0; lane < 64; ++lane) {
-              const int co = slab * slab_ch + wv * 16 * f_cm + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
+              const int co = slab * slab_ch + wv * 16 * f_cm + wreg_row(m, lane & 15), kk = c * 32 + (lane >> 4) * 8;
               for (int q = 0; q < 8; ++q) frag[d++] = src[(size_t)co * L->k_pad + kk + q];
             }
     e = hipMalloc(&L->wfrag, n * 2);

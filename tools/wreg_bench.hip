@@ -70,7 +70,7 @@ int run(int R) {
         for (int c = 0; c < 2 * KC; ++c)
           for (int m = 0; m < CM; ++m)
             for (int lane = 0; lane < 64; ++lane) {
-              const int co = slab * slab_ch + wv * 16 * CM + m * 16 + (lane & 15), kk = c * 32 + (lane >> 4) * 8;
+              const int co = slab * slab_ch + wv * 16 * CM + (CM == 2 ? wreg_row(m, lane & 15) : m * 16 + (lane & 15)), kk = c * 32 + (lane >> 4) * 8;
               for (int q = 0; q < 8; ++q) hf[d++] = hw[(size_t)co * K + kk + q];
             }
   }
@@ -119,6 +119,6 @@ int run(int R) {
 
 int main(int argc, char** argv) {
   const int R = argc > 1 ? atoi(argv[1]) : 77056, K = argc > 2 ? atoi(argv[2]) : 512;
-  if (K == 512) { run<8, 2, 8>(R); printf("-- one wave per SIMD, 64 channels per wave --\n"); return run<8, 4, 4>(R); }
+  if (K == 512) return run<8, 2, 8>(R);   // (<8, 4, 4>, one wave per SIMD: profiles/r02_wreg_one_wave_per_simd.log)
   return run<24, 2, 4>(R);
 }
