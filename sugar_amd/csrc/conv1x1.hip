@@ -345,6 +345,187 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, in
   else gemm_tile<256, 256, NS, PP>(a, co_base, r_tile);
 }
 
+// ---- persistent form of the split-tail grid (the wide convs: catconv, the 1024-channel convs) -----------------------
+// One workgroup per CU walks its 256 x 256 tiles round by round (ping-pong schedule, same sums in the same order as
+// gemm_tile<256, 256, 2, 1>: bit-identical) and then takes its sub-tile of the split tail.  What the loop buys over one
+// workgroup per tile: (i) the first k-tile of the NEXT tile is DMA'd into stage 0 while the epilogue of the current one
+// runs out of stage 1 + the 32 KiB the two stages leave free, so no tile but the first waits for a DMA round trip before
+// its first MFMA; (ii) the epilogue's 16 stores per wave drain under the next tile's k-loop instead of holding the CU
+// until the workgroup has exited (one workgroup fits a CU: the next one could not start before).
+// vmcnt bookkeeping: vector memory operations of a wave return in issue order, and the prefetch is issued BEFORE the
+// epilogue's stores, so "my share of the prefetch has landed" is vmcnt(<stores issued since>): 16 for a full tile
+// without a duplicate store, otherwise the wave just waits for everything.
+template <int dummy = 0>
+__device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const int xcd_first, const int stride, const int rounds) {
+  constexpr int TM = 256, TN = 256, STAGE_BYTES = (TM + TN) * 128;
+  constexpr int MI = TM / 32, NJ = TN / 64, CW = TM / 2, FW = TN / 4, WI = TM / 64, XI = TN / 64;
+  constexpr int EPI_STRIDE = CW * 2 + 16, HN = 2;
+  constexpr int CPR = CW / 8, RPP = 64 / CPR, NSTORE = (NJ / HN) * (16 * HN / RPP);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;
+  const int srow = lane >> 3, fr = lane & 15, fq = lane >> 4;
+  const int nk = a.K / TK;
+  const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
+
+  // folded-BN vectors of ALL output channels in LDS behind the staging: a global load in the epilogue would be younger
+  // than the prefetch in flight, and waiting for it (in-order returns) would expose the very round trip the prefetch hides
+  float* bn = (float*)(smem + STAGE_BYTES + 8 * (16 * HN * EPI_STRIDE));
+  if (affine) {
+    for (int i = tid; i < a.cout; i += 512) {
+      bn[i] = a.scale[i];
+      bn[a.cout + i] = a.shift[i];
+    }
+  }
+  // DMA sources of the tile being staged (k-tile 0): each wave its rows of both operands, 8 rows (1 KiB) per instruction
+  const bf16* wsrc[WI];
+  const bf16* xsrc[XI];
+  auto point_at = [&](int co_base, int r_base) {
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int row = wv * (WI * 8) + i * 8 + srow;
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);        // source chunk that belongs at LDS position lane & 7
+      wsrc[i] = a.w + (size_t)(co_base + row) * a.ldw + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int row = wv * (XI * 8) + i * 8 + srow;
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const int xr = min(r_base + row, a.R - 1);              // rows past R: any valid row, masked at the store
+      xsrc[i] = a.x + (size_t)xr * a.ldx + chunk * 8;
+    }
+  };
+  auto stage = [&](int buf, int kt) {
+    unsigned char* wbase = smem + buf * STAGE_BYTES + wv * (WI * 8) * 128;
+    unsigned char* xbase = smem + buf * STAGE_BYTES + TM * 128 + wv * (XI * 8) * 128;
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * TK),
+                                       (__attribute__((address_space(3))) void*)(wbase + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + kt * TK),
+                                       (__attribute__((address_space(3))) void*)(xbase + i * 1024), 16, 0, 0);
+  };
+  auto tile_at = [&](int r, int& co_base, int& r_base) {
+    const int vid = xcd_first + r * stride;
+    co_base = (vid % a.n_co_tiles) * TM;
+    r_base = (vid / a.n_co_tiles) * TN;
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int m = 0; m < MI; ++m)
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int co_base, r_base;
+  tile_at(0, co_base, r_base);
+  point_at(co_base, r_base);
+  stage(0, 0);
+  bool counted = false;                                        // the wait below may leave NSTORE younger stores in flight
+  for (int r = 0; r < rounds; ++r) {
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // k-tile 0 in stage 0; every wave out of its epilogue
+    if (wm) asm volatile("s_barrier" ::: "memory");             // group 1 idles through phase 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* wb = smem + (kt & 1) * STAGE_BYTES;
+      const unsigned char* xb = wb + TM * 128;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[MI], bf[NJ];
+        if (s == 0 && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) af[m] = *(const bf16x8*)(wb + swz(wm * CW + m * 16 + fr, 4 * s + fq));
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) bf[n] = *(const bf16x8*)(xb + swz(wn * FW + n * 16 + fr, 4 * s + fq));
+        if (s == 1 && wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+          for (int n = 0; n < NJ; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 1 && !wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(wm && s == 1 && kt + 1 == nk)) asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // every wave is past the last LDS read of stage 0 (k-tile nk - 2; nk is even): the next tile's first k-tile goes there
+    const int co_cur = co_base, r_cur = r_base;
+    if (r + 1 < rounds) {
+      tile_at(r + 1, co_base, r_base);
+      point_at(co_base, r_base);
+      stage(0, 0);
+    }
+    counted = r_cur + TN <= a.R && co_cur + TM <= a.cout && !a.y2;   // exactly NSTORE stores follow, none masked off
+    // ---- epilogue out of stage 1 + the free tail of LDS (gemm_tile's, with the staging moved) -------------------
+    unsigned char* ep = smem + STAGE_BYTES + wv * (16 * HN * EPI_STRIDE);
+#pragma unroll
+    for (int pass = 0; pass < NJ / HN; ++pass) {
+#pragma unroll
+      for (int m = 0; m < MI; ++m) {
+        const int col = m * 16 + 4 * fq;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (affine) {
+          sc = *(const f32x4*)(bn + co_cur + wm * CW + col);
+          sh = *(const f32x4*)(bn + a.cout + co_cur + wm * CW + col);
+        }
+#pragma unroll
+        for (int nn = 0; nn < HN; ++nn) {
+          f32x4 v = acc[m][pass * HN + nn];
+          acc[m][pass * HN + nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          v = v * sc + sh;
+          if (tanh_) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+          }
+          const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4*)(ep + (nn * 16 + fr) * EPI_STRIDE + col * 2) = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 16 * HN / RPP; ++i) {
+        const int f = i * RPP + lane / CPR;
+        const int ch = lane % CPR;
+        const int rr = r_cur + wn * FW + pass * (16 * HN) + f;
+        const int co = co_cur + wm * CW + ch * 8;
+        const u32x4 v = *(const u32x4*)(ep + f * EPI_STRIDE + ch * 16);
+        if (rr < a.R && co < a.cout) {
+          *(u32x4*)(a.y + (size_t)rr * a.ldy + co) = v;
+          if (a.y2 && co >= a.y2_from) *(u32x4*)(a.y2 + (size_t)rr * a.ldy2 + co) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // staging free before a tail sub-tile reuses the stages
+}
+
+// grid = the CU count (a multiple of 8); n_main = rounds * grid tiles of 256 x 256, then `tail` tiles cut into `split`
+__global__ __launch_bounds__(512, 2) void gemm1x1_persist_kernel(Gemm1x1Args a, int n_main, int split, int tail) {
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int xcd = bid & 7, seq = bid >> 3, wpx = nwg >> 3, rounds = n_main / nwg;
+  // XCD x owns the contiguous tile range [x rounds wpx, (x + 1) rounds wpx); in round r its workgroups take consecutive
+  // tiles of it, so co-tiles that share an activation row tile run at the same time on one XCD (shared L2)
+  gemm_tiles_persist<0>(a, xcd * rounds * wpx + seq, wpx, rounds);
+  if (bid >= tail * split) return;
+  const int tile = n_main + bid / split, sub = bid - (bid / split) * split;
+  const int co_base = (tile % a.n_co_tiles) * 256, r_tile = (tile / a.n_co_tiles) * 256;
+  if (split == 4) gemm_tile<256, 64, 2, 1>(a, co_base, r_tile + sub * 64);
+  else if (split == 2) gemm_tile<256, 128, 2, 1>(a, co_base, r_tile + sub * 128);
+  else gemm_tile<256, 256, 2, 1>(a, co_base, r_tile);
+}
+
 template <int TM, int TN, int NS, int PP = 0>
 int launch_variant(const Gemm1x1Args& a, hipStream_t s) {
   constexpr int smem = NS * (TM + TN) * 128;
@@ -366,6 +547,16 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
   const int total = a.n_co_tiles * (int)ceil_div(a.R, 256);
   const int n_main = total / n_cu * n_cu, tail = total - n_main;
   const int split = tail == 0 ? 1 : tail * 4 <= n_cu ? 4 : tail * 2 <= n_cu ? 2 : 1;
+  if (PP == 1 && n_main >= 2 * n_cu && n_cu % 8 == 0 && (a.K / TK) % 2 == 0 && !a.xmap && a.cout <= 3072 && a.cout % 4 == 0 &&
+      !tune_get(TUNE_GEMM_NO_PERSIST)) {
+    // two rounds or more: one persistent workgroup per CU (stage 1 + 8 x 8 704 bytes of epilogue staging behind it)
+    constexpr int psmem = (256 + 256) * 128 + 8 * (16 * 2 * (128 * 2 + 16)) + 2 * 3072 * 4;   // + folded-BN vectors
+    static OptInMask popted{0};
+    if (int rc = lds_opt_in((const void*)gemm1x1_persist_kernel, psmem, &popted)) return rc;
+    hipLaunchKernelGGL(gemm1x1_persist_kernel, dim3(n_cu), dim3(512), psmem, s, a, n_main, split, tail);
+    SUGAR_LAUNCH_CHECK();
+    return SUGAR_OK;
+  }
   hipLaunchKernelGGL((gemm1x1_split_kernel<2, PP>), dim3(n_main + tail * split), dim3(512), smem, s, a, n_main, split);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;

@@ -129,15 +129,21 @@ def test_pool1_weights_in_registers_is_bit_identical_to_tiles(frames):
     assert _rel(wreg, want) < 6e-3
 
 
-def test_wide_gemm_schedules_are_bit_identical():
-    """catconv shape with full 256 x 256 rounds: ping-pong + split tail (what the forward runs) == in-step == uniform grid."""
-    case = (1536, 1536, 1, 1, 1, [301] * 40)
+@pytest.mark.parametrize("frames", [[301] * 40, [301] * 100, [301] * 110 + [70]], ids=["1round", "2rounds+tail", "3rounds+split4"])
+def test_wide_gemm_schedules_are_bit_identical(frames):
+    """catconv shape with full 256 x 256 rounds.  What the forward runs -- ping-pong schedule, split tail, and from two
+    rounds up ONE persistent workgroup per CU that prefetches its next tile's first k-tile under the epilogue -- against
+    one workgroup per tile, the in-step schedule and the uniform grid: the same bytes, and F.conv1d within bf16."""
+    case = (1536, 1536, 1, 1, 1, frames)
     pp, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
+    with _lib.tuned(gemm_no_persist=1):
+        per_tile, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
     with _lib.tuned(gemm_no_pingpong=1):
         instep, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
     with _lib.tuned(gemm_uniform=1):
         uniform, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
-    assert torch.equal(pp, instep) and torch.equal(pp, uniform)
+    assert torch.isfinite(pp).all()
+    assert torch.equal(pp, per_tile) and torch.equal(pp, instep) and torch.equal(pp, uniform)
     assert _rel(pp, want) < 6e-3
 
 

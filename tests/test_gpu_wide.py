@@ -57,3 +57,20 @@ def test_1024_channel_batch_is_deterministic_and_batch_invariant(wide_supernet):
     small = model(wav.to(DEV))
     assert torch.isfinite(big).all() and torch.equal(model(wav.repeat(16, 1).to(DEV)), big)
     assert torch.equal(big.view(16, 4, 192), small.unsqueeze(0).expand(16, 4, 192))
+
+
+def test_1024_channel_persistent_gemm_is_bit_identical_to_one_workgroup_per_tile(wide_supernet):
+    """176 x 3 s through the 1024-channel supernet: R = 52 976 frames = 828 tiles of 256 x 256 in the 1024 -> 1024 convs
+    (three rounds + a split tail), so first_conv (with its duplicate store of the 8th Res2 split), last_conv and
+    catconv all take the persistent GEMM; one workgroup per tile must give the same embeddings bit for bit."""
+    from sugar_amd import _lib
+    sub = wide_supernet.clone(WIDE["full"]).set_precision("bf16")
+    wide_supernet.config = None
+    model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(DEV).eval()
+    wav = synth.waveforms(4, 48000, seed=0).repeat(44, 1).to(DEV)
+    persistent = model(wav)
+    with _lib.tuned(gemm_no_persist=1):
+        per_tile = model(wav)
+    assert torch.isfinite(persistent).all() and torch.equal(persistent, per_tile)
+    small = model(wav[:4])
+    assert torch.equal(persistent.view(44, 4, 192), small.unsqueeze(0).expand(44, 4, 192))

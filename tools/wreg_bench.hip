@@ -93,7 +93,7 @@ int run(int R) {
   a.y = y;
   a.wfrag = wfrag;
   struct V { const char* name; int (*fn)(const Gemm1x1Args&, hipStream_t); };
-  const V vs[] = {{"SK1", launch_wreg<KC, CM, 1, NW>}, {"SK2", launch_wreg<KC, CM, 2, NW>}, {"SK4", launch_wreg<KC, CM, 4, NW>}};
+  const V vs[] = {{"SK2", launch_wreg<KC, CM, 2, NW>}, {"SK4", launch_wreg<KC, CM, 4, NW>}, {"SK8", launch_wreg<KC, CM, 8, NW>}};
   for (const V& v : vs) {
     CK(hipMemset(y, 0, (size_t)R * N * 2));
     v.fn(a, 0);
