@@ -117,6 +117,12 @@ struct DT<bf16> {
   static constexpr int EPC = 8;
 };
 
+// v of another lane of the same 16-lane DPP row (CTRL: a DPP control, e.g. 0xB1 = quad_perm [1,0,3,2])
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
 template <typename T>
