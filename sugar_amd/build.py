@@ -16,30 +16,33 @@ HEADERS = ["common.h", os.path.join("..", "..", "include", "sugar_amd.h")]
 LIB = os.path.join(HERE, "libsugar_amd.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=on"]
-# Packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) are switched off for the whole library:
-# on MI355X a wave's packed-FP32 results were occasionally wrong while ANOTHER wave on the same CU issued MFMAs
-# (tools/fbank_corun.hip: the front-end kernel against a pure-MFMA burner on a second stream, 62 560 disagreeing
-# spectrum bins in 600 launches; 0 with the feature off; 0 against VALU / LDS / memory burners).  Two HIP streams
-# (extract_vectors, bench.py's pipelined leg) put exactly that mix on a CU.  DESIGN.md section 5b.
+# Packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): on MI355X a wave's packed-FP32 results were
+# occasionally wrong while ANOTHER wave on the same CU issued MFMAs (tools/fbank_corun.hip: the front-end kernel against a
+# pure-MFMA burner on a second stream, 62 560 disagreeing spectrum bins in 600 launches; 0 against VALU / LDS / memory
+# burners).  Two HIP streams (extract_vectors, bench.py's pipelined leg) put exactly that mix on a CU.  DESIGN.md 5b.
+# tools/pkfp32_probe.hip isolated the fault to ONE operand form: the op_sel bit of src1 set (the low result takes the
+# HIGH half of src1; 1 wrong result in 13 000 beside an MFMA burner, always lanes 48-63).  The feature stays OFF for the
+# library, with one exception: the front-end (fbank.hip) writes its complex butterflies as v_pk_* inline asm (the kernel
+# was VALU-bound and complex arithmetic is two-lane by nature), so the assembler must know the instructions and that file
+# is compiled with the feature on.  Every build then reads the device ISA of such a file and refuses any packed-FP32
+# instruction -- hand-written or picked by hipcc -- whose form is not in PACKED_FP32_SAFE: forms that ran 1.3e10 times
+# each beside the burner with 0 wrong results (profiles/r02_pkfp32_probe_forms.log; the faulty form is the log's
+# positive control).  SUGAR_PACKED_FP32_ALL=1 compiles every source that way (all 2 136 instructions hipcc then picks
+# are in cleared forms; measured in one job: 1.248 ms per step either way, so it is not the default).
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-# Exception, checked at every build: the front-end (fbank.hip) writes its complex butterflies as v_pk_* inline asm in the
-# operand forms the probe (tools/pkfp32_probe.hip, 1.3e10 executions each beside an MFMA burner) found clean, so the
-# assembler must know the instructions: that file is compiled with the feature ON, and _check_packed_forms() then reads
-# its ISA and fails the build if ANY packed-FP32 instruction (hand-written or chosen by the compiler) is not in one of
-# those forms.  The faulty form is "the low result takes the high half of src1" (op_sel bit of src1 set).
-PACKED_FP32_FILES = {"fbank.hip"}
 PACKED_FP32_SAFE = {
     "",                                                  # no modifiers
     "neg_lo:[0,1] neg_hi:[0,1]", "neg_hi:[0,1]", "neg_lo:[0,1]",       # negations of src1
+    "op_sel_hi:[1,0]", "op_sel_hi:[0,1]",                # low half of src1 / src0 for both results
+    "op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]",
+    "op_sel_hi:[1,0,1]", "op_sel_hi:[0,1,1]", "op_sel_hi:[1,1,0]",     # FMA, low-half broadcasts
+    "op_sel:[1,0,0]",                                    # FMA, high half of src0 for both results
     "op_sel:[1,0] op_sel_hi:[0,1]",                      # half swap of src0
     "op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]", "op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]",
     "op_sel:[1,0,0] op_sel_hi:[0,1,1]",                  # FMA, half swap of src0
 }
-EXTRA_FLAGS = {}
-if os.environ.get("SUGAR_ALLOW_PACKED_FP32") is None:
-    for _s in SOURCES:
-        if _s not in PACKED_FP32_FILES:
-            EXTRA_FLAGS[_s] = NO_PACKED_FP32
+PACKED_FP32_FILES = set(SOURCES) if os.environ.get("SUGAR_PACKED_FP32_ALL") else {"fbank.hip"}
+EXTRA_FLAGS = {_s: NO_PACKED_FP32 for _s in SOURCES if _s not in PACKED_FP32_FILES}
 
 
 def _check_packed_forms(hipcc, src):
@@ -48,7 +51,7 @@ def _check_packed_forms(hipcc, src):
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "isa.s")
-        subprocess.check_call([hipcc] + FLAGS + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out],
+        subprocess.check_call([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         bad, n = [], 0
         for line in open(out):
@@ -95,11 +98,19 @@ def build(force=False, verbose=True):
         failed |= p.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
-    if os.environ.get("SUGAR_ALLOW_PACKED_FP32") is None:
-        for src in sorted(PACKED_FP32_FILES):
-            n = _check_packed_forms(hipcc, src)
-            if verbose:
-                print("[packed FP32] %s: %d instructions, all in probe-cleared forms" % (src, n))
+    checks = [(src, subprocess.Popen([sys.executable, "-c",
+                                      "import sys; sys.path.insert(0, %r); from sugar_amd import build; "
+                                      "print(build._check_packed_forms(%r, %r))" % (os.path.dirname(HERE), hipcc, src)],
+                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+              for src in sorted(PACKED_FP32_FILES)]
+    total = 0
+    for src, p in checks:
+        out, err = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(err.strip().splitlines()[-1] if err.strip() else "packed-FP32 check failed for " + src)
+        total += int(out.strip())
+    if verbose:
+        print("[packed FP32] %d instructions in %d files, all in probe-cleared forms" % (total, len(checks)))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 

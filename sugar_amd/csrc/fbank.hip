@@ -34,7 +34,6 @@ constexpr int SPAN = (FRAMES - 1) * HOP + WIN;   // 5360 samples
 constexpr int MEL_MAXW = 20;              // table row length: max non-zero taps of one mel filter (16 for this filterbank)
 constexpr int MEL_W0 = 10;                // filters 0..63 have at most 10 taps: lane j projects filter j
 constexpr int MEL_W1 = 4;                 // filters 64..79 (<= 16 taps): lane j takes taps 4 (j & 3) .. + 3 of filter 64 + j / 4
-constexpr int SLD = NMEL + 1;
 
 struct FbankTables {
   float2* tw = nullptr;      // [512] exp(-2 pi i n / 512)

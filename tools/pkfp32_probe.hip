@@ -63,6 +63,23 @@ __global__ __launch_bounds__(256) void probe(int iters, Stat* st) {
                   e.x = sfma(x.x, y.x, z.x); e.y = sfma(x.y, y.y, z.y); u = e; }
     if (V == 16) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
                   e.x = smul(x.x, y.x); e.y = smul(x.y, y.y); u = e; }
+    // forms hipcc itself picks for scalar code when the feature is on (low-half broadcasts: every op_sel bit 0)
+    if (V == 17) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y));
+                  e.x = smul(x.x, y.x); e.y = smul(x.y, y.x); u.x = e.x; u.y = smul(x.y, y.y); }
+    if (V == 18) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+                  e.x = sfma(x.x, y.x, z.x); e.y = sfma(x.y, y.x, z.y); u.x = e.x; u.y = sfma(x.y, y.y, z.y); }
+    if (V == 19) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+                  e.x = sfma(x.x, y.x, z.x); e.y = sfma(x.x, y.y, z.y); u.x = e.x; u.y = sfma(x.y, y.y, z.y); }
+    if (V == 20) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+                  e.x = sfma(x.x, y.x, z.x); e.y = sfma(x.y, y.y, z.x); u.x = e.x; u.y = sfma(x.y, y.y, z.y); }
+    if (V == 21) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+                  e.x = sadd(x.x, y.x); e.y = sadd(x.x, y.y); u.x = e.x; u.y = sadd(x.y, y.y); }
+    if (V == 23) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z));   // broadcast x.hi
+                  e.x = sfma(x.y, y.x, z.x); e.y = sfma(x.y, y.y, z.y); u.x = sfma(x.x, y.x, z.x); u.y = e.y; }
+    if (V == 24) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+                  e.x = sadd(x.x, -y.x); e.y = sadd(x.x, -y.y); u.x = e.x; u.y = sadd(x.y, -y.y); }
+    if (V == 22) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+                  e.x = smul(x.x, y.x); e.y = smul(x.x, y.y); u.x = e.x; u.y = smul(x.y, y.y); }
     if (r.x != e.x || r.y != e.y) {
       atomicAdd(&st->quarter[(threadIdx.x & 63) >> 4], 1u);
       if (r.x == u.x && r.y == u.y) atomicAdd(&st->unswapped, 1u); else atomicAdd(&st->other, 1u);
@@ -141,6 +158,14 @@ int main(int argc, char** argv) {
     run<14>("v_pk_add_f32 neg_hi:[0,1]", reps, a, b, st, sink);
     run<15>("v_pk_fma_f32 (no modifiers)", reps, a, b, st, sink);
     run<16>("v_pk_mul_f32 (no modifiers)", reps, a, b, st, sink);
+    run<17>("v_pk_mul_f32 op_sel_hi:[1,0]", reps, a, b, st, sink);
+    run<18>("v_pk_fma_f32 op_sel_hi:[1,0,1]", reps, a, b, st, sink);
+    run<19>("v_pk_fma_f32 op_sel_hi:[0,1,1]", reps, a, b, st, sink);
+    run<20>("v_pk_fma_f32 op_sel_hi:[1,1,0]", reps, a, b, st, sink);
+    run<21>("v_pk_add_f32 op_sel_hi:[0,1]", reps, a, b, st, sink);
+    run<22>("v_pk_mul_f32 op_sel_hi:[0,1]", reps, a, b, st, sink);
+    run<23>("v_pk_fma_f32 op_sel:[1,0,0]", reps, a, b, st, sink);
+    run<24>("v_pk_add_f32 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]", reps, a, b, st, sink);
     run<0>("v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (control)", reps, a, b, st, sink);
     return 0;
   }
