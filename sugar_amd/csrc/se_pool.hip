@@ -251,14 +251,21 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(const float* __restri
   for (int u = 0; u < TAIL_U; ++u) acc[u] = 0.f;
   const bool o_ok = o < embed;
   const float* wcol = wt + (size_t)k0 * embed + (o_ok ? o : 0);
-#pragma unroll 8
-  for (int i = kl; i < kn; i += 4) {
-    const float w = o_ok ? wcol[(size_t)i * embed] : 0.f;
+  // all of a thread's weights (<= TAIL_K / 4 = 32) are requested before the first is used: with 8 at a time a wave paid
+  // four L2 round trips in a row and lived 9 us; rows past kn are clamped to a valid one and masked
+  constexpr int NW = TAIL_K / 4;
+  float w[NW];
+#pragma unroll
+  for (int n = 0; n < NW; ++n) w[n] = wcol[(size_t)min(kl + 4 * n, kn - 1) * embed];
+#pragma unroll
+  for (int n = 0; n < NW; ++n) {
+    const int i = kl + 4 * n;
+    const float wn = o_ok && i < kn ? w[n] : 0.f;
 #pragma unroll
     for (int u4 = 0; u4 < TAIL_U / 4; ++u4) {
-      const f32x4 pv = *(const f32x4*)&ps[i][4 * u4];
+      const f32x4 pv = *(const f32x4*)&ps[min(i, TAIL_K - 1)][4 * u4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[4 * u4 + e] = fmaf(w, pv[e], acc[4 * u4 + e]);
+      for (int e = 0; e < 4; ++e) acc[4 * u4 + e] = fmaf(wn, pv[e], acc[4 * u4 + e]);
     }
   }
 #pragma unroll
