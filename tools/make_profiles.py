@@ -69,7 +69,7 @@ tj = {"_source": "round %s, tools/profile_round.sh (bench.py --steps 3 --warmup 
       "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     tj["kernels"][k] = {"fetch": int(fetch.get(k, 0) * 1024 * 2), "write": int(write.get(k, 0) * 1024)}
-cat = [k for k in tj["kernels"] if k.startswith("gemm1x1_split_kernel")]
+cat = [k for k in tj["kernels"] if k.startswith(("gemm1x1_persist_kernel", "gemm1x1_split_kernel"))]
 assert len(cat) == 1
 tj["base256_bf16"] = tj["kernels"][cat[0]]["fetch"] + tj["kernels"][cat[0]]["write"]
 json.dump(tj, open(os.path.join(out, "traffic_catconv.json"), "w"), indent=1)
