@@ -327,12 +327,214 @@ int r2_smem_bytes(int t_max, int wp, int halo, int k_pad) {
   return ((u_rows * wp * 2 + 255) & ~255) + 64 * k_pad * 2 + R2_WAVES * ot * 16 * wp * 2 + R2_STEPS * 128 * 4;
 }
 
+
+// ---- wide groups (64 < w <= 128: the 1024-channel backbones) -------------------------------------------------------
+// Same chain, same sums, another decomposition: a step's weight panel [w][k_pad] (up to 128 x 640 bf16 = 160 KiB) does not
+// fit LDS next to the utterance's u tile (up to 100 KiB), so a step runs as NSUB sub-passes over 16 SUBM output channels
+// each, whose weights (<= 48 KiB) are staged while the previous sub-pass computes.  The two MFMA tiles of a channel pair
+// are interleaved as in the weights-in-registers GEMM (wreg_row): lane (f, q) then owns 8 consecutive channels of its
+// frames, so sp_j goes to global memory and into u_{j+1} = x_{j+1} + sp_j as 16-byte chunks straight from the
+// accumulators -- no staging tile (there is no LDS left for one).  x_{j+1} is prefetched in that same lane layout.
+template <int SUBM, int WREG>
+__global__ __launch_bounds__(512, 2) void res2_wide_kernel(Res2Args a) {
+  constexpr int R2_WAVES = 8, TPW = 3, SUBC = 16 * SUBM, NP = SUBM / 2, NSUB_MAX = 128 / SUBC, NPG = 4;
+  static_assert(SUBM == 2 || SUBM == 4, "whole channel pairs per sub-pass");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int wp = a.wp, ctr = (a.ktaps - 1) >> 1, halo = ctr * a.dil;
+  const int u0 = a.row_off[b], Tu = a.row_off[b + 1] - u0;
+  const int nseg = Tu <= a.max_t ? 1 : (Tu + a.seg_inner - 1) / a.seg_inner;
+  if ((int)blockIdx.y >= nseg) return;
+  const int inner = nseg == 1 ? Tu : (((Tu + nseg - 1) / nseg + 15) & ~15);
+  const int t0 = blockIdx.y * inner, t1 = min(Tu, t0 + inner);
+  if (t0 >= t1) return;
+  const int ctx = R2_STEPS * halo;
+  const int p0 = max(0, t0 - ctx), p1 = min(Tu, t1 + ctx);
+  const int s0 = u0 + p0, T = p1 - p0, st_lo = t0 - p0, st_hi = t1 - p0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int f = lane & 15, q = lane >> 4;
+  const int NT = (T + 15) >> 4;
+  const int urow = wp * 2, nch = wp >> 3, nsub = wp / SUBC, npg = wp >> 5;
+  const int swz_mask = (nch & (nch - 1)) == 0 ? 7 : 0;
+  const int u_rows = NT * 16 + 2 * halo;
+  const int u_bytes = (u_rows * urow + 255) & ~255;
+  const int wstride = a.k_pad * 2, wchunks = a.k_pad >> 3, nks = a.k_pad >> 5;
+  unsigned char* u = smem;
+  unsigned char* wl = smem + u_bytes;
+  float* ss = (float*)(wl + SUBC * wstride);            // [7][scale 128 | shift 128]
+
+  for (int i = tid; i < u_bytes / 16; i += 512) ((u32x4*)u)[i] = (u32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < R2_STEPS * 256; i += 512) {
+    const int j = i >> 8, c = i & 127;
+    ss[i] = (i & 128) ? a.shift[j][c] : a.scale[j][c];
+  }
+  int ntw = 0;
+#pragma unroll
+  for (int n = 0; n < TPW; ++n) ntw += (wv + R2_WAVES * n) < NT;
+
+  // weight staging: chunk idx = tid + 512 i of a sub-pass's [SUBC][wchunks] panel; LDS row 16 m + i holds channel
+  // 32 (m / 2) + wreg_row(m % 2, i) of the sub-pass
+  int wsrc[WREG], wdst[WREG];
+#pragma unroll
+  for (int i = 0; i < WREG; ++i) {
+    const int idx = tid + 512 * i;
+    const int row = idx / wchunks, c = idx - row * wchunks;
+    const int ch = 32 * (row >> 5) + wreg_row((row >> 4) & 1, row & 15);
+    wsrc[i] = idx < SUBC * wchunks ? ch * a.k_pad + c * 8 : -1;
+    wdst[i] = row * wstride + (((c & ~7) | ((c & 7) ^ (row & 7))) << 4);
+  }
+  u32x4 wreg[WREG];
+  auto load_w = [&](int j, int sub) {
+    const bf16* wb = a.w[j] + (size_t)sub * SUBC * a.k_pad;
+#pragma unroll
+    for (int i = 0; i < WREG; ++i) wreg[i] = *(const u32x4*)(wb + max(wsrc[i], 0));
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < WREG; ++i)
+      if (wsrc[i] >= 0) *(u32x4*)(wl + wdst[i]) = wreg[i];
+  };
+
+  const bf16* xb = a.x + (size_t)s0 * a.ld;
+  bf16* yb = a.y + (size_t)s0 * a.ld;
+  // xs[n][pg]: channels 32 pg + 8 q .. + 7 of frame 16 (wv + 8 n) + f: x_{j+1} during step j, turned in place into u_{j+1}
+  u32x4 xs[TPW][NPG];
+  auto load_x = [&](int j) {
+#pragma unroll
+    for (int n = 0; n < TPW; ++n)
+#pragma unroll
+      for (int pg = 0; pg < NPG; ++pg) {                 // clamped (always valid) addresses; unused items are never stored
+        const int r = min((wv + R2_WAVES * n) * 16 + f, T - 1);
+        xs[n][pg] = *(const u32x4*)(xb + r * a.ld + j * wp + min(4 * pg + q, nch - 1) * 8);
+      }
+  };
+  auto write_u = [&]() {
+#pragma unroll
+    for (int n = 0; n < TPW; ++n)
+#pragma unroll
+      for (int pg = 0; pg < NPG; ++pg) {
+        const int r = (wv + R2_WAVES * n) * 16 + f;
+        if (n < ntw && pg < npg && r < T) {
+          const int row = r + halo;
+          *(u32x4*)(u + row * urow + (((4 * pg + q) ^ (row & swz_mask)) << 4)) = xs[n][pg];
+        }
+      }
+  };
+
+  const int inv_wp = (65536 + wp - 1) / wp;
+  load_w(0, 0);
+  load_x(0);                                            // u_0 = x_0
+  __syncthreads();                                      // zero fill complete before the first u write
+  write_u();
+  store_w();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int j = 0; j < R2_STEPS; ++j) {
+    const bool last = j + 1 == R2_STEPS;
+    if (!last) load_x(j + 1);                           // in flight during the first sub-pass
+#pragma unroll
+    for (int sub = 0; sub < NSUB_MAX; ++sub) {
+      if (sub < nsub) {
+        const bool more_sub = sub + 1 < nsub;
+        if (more_sub) load_w(j, sub + 1);
+        else if (!last) load_w(j + 1, 0);
+        f32x4 acc[TPW][SUBM];
+#pragma unroll
+        for (int n = 0; n < TPW; ++n)
+#pragma unroll
+          for (int m = 0; m < SUBM; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int ks_ld = 0;
+        auto load_frags = [&](bf16x8 (&af)[SUBM], bf16x8 (&bf)[TPW]) {
+          const int c = 4 * ks_ld + q;                    // this lane's K chunk
+          const int tap = (c * 8 * inv_wp) >> 16, ci = c * 8 - tap * wp;
+          const bool kpad = tap >= a.ktaps || ks_ld >= nks;
+          const int roff = halo + (kpad ? 0 : (tap - ctr) * a.dil);
+          const int cch = kpad ? 0 : (ci >> 3);
+          const int cw = ks_ld < nks ? c : q;
+#pragma unroll
+          for (int m = 0; m < SUBM; ++m)
+            af[m] = *(const bf16x8*)(wl + (m * 16 + f) * wstride + (((cw & ~7) | ((cw & 7) ^ (f & 7))) << 4));
+#pragma unroll
+          for (int n = 0; n < TPW; ++n) {
+            const int row = (n < ntw ? (wv + R2_WAVES * n) * 16 : 0) + f + roff;
+            bf[n] = *(const bf16x8*)(u + row * urow + ((cch ^ (row & swz_mask)) << 4));
+          }
+          ++ks_ld;
+        };
+        auto mma = [&](const bf16x8 (&af)[SUBM], const bf16x8 (&bf)[TPW]) {
+#pragma unroll
+          for (int n = 0; n < TPW; ++n)
+            if (n < ntw) {
+#pragma unroll
+              for (int m = 0; m < SUBM; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[n][m], 0, 0, 0);
+            }
+        };
+        {
+          bf16x8 af0[SUBM], bf0[TPW], af1[SUBM], bf1[TPW];
+          load_frags(af0, bf0);
+          for (int ks = 0; ks < nks; ks += 2) {
+            load_frags(af1, bf1);
+            mma(af0, bf0);
+            load_frags(af0, bf0);
+            mma(af1, bf1);
+          }
+        }
+        // epilogue of the sub-pass: ReLU -> folded BN -> bf16, 8 consecutive channels per lane and frame
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+          const int pg = sub * NP + pp;
+          const int cb = 32 * pg + 8 * q;                 // first of this lane's 8 channels
+          const f32x4 sc0 = *(const f32x4*)(ss + j * 256 + cb), sc1 = *(const f32x4*)(ss + j * 256 + cb + 4);
+          const f32x4 sh0 = *(const f32x4*)(ss + j * 256 + 128 + cb), sh1 = *(const f32x4*)(ss + j * 256 + 128 + cb + 4);
+#pragma unroll
+          for (int n = 0; n < TPW; ++n) {
+            if (n < ntw) {
+              f32x4 v0 = acc[n][2 * pp], v1 = acc[n][2 * pp + 1];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+              v0 = v0 * sc0 + sh0;
+              v1 = v1 * sc1 + sh1;
+              const bf16x8 o = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+              const u32x4 sp = __builtin_bit_cast(u32x4, o);
+              const int r = (wv + R2_WAVES * n) * 16 + f;
+              if (r < T && cb < wp) {
+                if (r >= st_lo && r < st_hi) *(u32x4*)(yb + r * a.ld + j * wp + cb) = sp;
+                if (!last) xs[n][pg] = add_bf16x8(xs[n][pg], sp);
+              }
+            }
+          }
+        }
+        // LDS-only barriers (see res2_chain_kernel): every wave has read this sub-pass's weights (and, behind the last
+        // sub-pass, u_j) before they are overwritten
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more_sub || !last) store_w();
+        if (!more_sub && !last) write_u();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+  }
+}
+
+int r2_wide_smem_bytes(int t_max, int wp, int halo, int k_pad, int subm) {
+  t_max = t_max < R2_MAX_T ? t_max : R2_MAX_T;
+  const int u_rows = (t_max + 15) / 16 * 16 + 2 * halo;
+  return ((u_rows * wp * 2 + 255) & ~255) + 16 * subm * k_pad * 2 + R2_STEPS * 256 * 4;
+}
+
+// m-tiles per sub-pass for this shape: 4 (64 channels) where LDS allows, else 2; 0 = the wide kernel cannot take it
+int r2_wide_subm(int t_max, int wp, int halo, int k_pad) {
+  if (wp <= 64 || wp > 128 || wp % 32 != 0 || k_pad > 640 || k_pad % 64 != 0) return 0;
+  if (wp % 64 == 0 && r2_wide_smem_bytes(t_max, wp, halo, k_pad, 4) <= 160 * 1024) return 4;
+  return r2_wide_smem_bytes(t_max, wp, halo, k_pad, 2) <= 160 * 1024 ? 2 : 0;
+}
+
 }  // namespace
 
 bool res2_chain_eligible(int dtype, int t_max, int wp, int k_pad, int n_pad) {
-  if (dtype != SUGAR_BF16 || t_max < 1 || wp > 64 || wp % 8 != 0 || n_pad != 64) return false;
+  if (dtype != SUGAR_BF16 || t_max < 1 || wp % 8 != 0) return false;
   if (tune_get(TUNE_GENERIC_RES2)) return false;    // A/B switch for the parity tests: force the per-step path
-  return k_pad <= 64 * 5 && r2_smem_bytes(t_max, wp, 10, k_pad) <= 160 * 1024;
+  if (wp > 64)                                      // wide groups: halo unknown here, 16 = 5 taps at dilation 4 ... 9 taps at 2
+    return n_pad == 128 && r2_wide_subm(t_max, wp, 16, k_pad) != 0;
+  return n_pad == 64 && k_pad <= 64 * 5 && r2_smem_bytes(t_max, wp, 10, k_pad) <= 160 * 1024;
 }
 
 int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld, int wp, const int32_t* d_row_off,
@@ -340,8 +542,9 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   Res2Args a;
   a.x = (const bf16*)d_x; a.y = (bf16*)d_y; a.row_off = d_row_off;
   a.ld = ld; a.wp = wp; a.ktaps = steps[0].ktaps; a.dil = steps[0].dil; a.k_pad = steps[0].k_pad;
+  const int n_pad = wp > 64 ? 128 : 64;
   for (int j = 0; j < R2_STEPS; ++j) {
-    SUGAR_CHECK_ARG(steps[j].k_pad == a.k_pad && steps[j].ktaps == a.ktaps && steps[j].scale && steps[j].n_pad == 64,
+    SUGAR_CHECK_ARG(steps[j].k_pad == a.k_pad && steps[j].ktaps == a.ktaps && steps[j].scale && steps[j].n_pad == n_pad,
                     "res2: inconsistent step %d", j);
     a.w[j] = (const bf16*)steps[j].w; a.scale[j] = steps[j].scale; a.shift[j] = steps[j].shift;
   }
@@ -360,6 +563,23 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   const int nseg_max = t_max <= a.max_t ? 1 : (int)ceil_div(t_max, a.seg_inner);
   SUGAR_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && (int64_t)R2_MAX_T * ld < (1ll << 31),
                   "res2: activations must be 16-byte aligned with ld %% 8 == 0 (ld %d)", ld);
+  if (wp > 64) {
+    const int subm = r2_wide_subm(t_max, wp, halo, a.k_pad);
+    SUGAR_CHECK_ARG(subm != 0 && halo <= 16, "res2: %d-channel groups with k_pad %d / halo %d do not fit the wide kernel", wp, a.k_pad, halo);
+    const int wsmem = r2_wide_smem_bytes(t_max, wp, halo, a.k_pad, subm);
+    const int wchunks = 16 * subm * (a.k_pad >> 3);
+#define R2_WIDE(SM, WR)                                                                                        \
+  {                                                                                                            \
+    static OptInMask opted{0};                                                                                 \
+    if (int rc = lds_opt_in((const void*)res2_wide_kernel<SM, WR>, 160 * 1024, &opted)) return rc;             \
+    hipLaunchKernelGGL((res2_wide_kernel<SM, WR>), dim3(B, nseg_max), dim3(512), wsmem, s, a);                 \
+  }
+    if (subm == 4) { if (wchunks <= 512 * 3) R2_WIDE(4, 3) else R2_WIDE(4, 6) }   // (64 x 384 / 8 = 3 072 chunks at most: LDS)
+    else { if (wchunks <= 512 * 3) R2_WIDE(2, 3) else R2_WIDE(2, 5) }
+#undef R2_WIDE
+    SUGAR_LAUNCH_CHECK();
+    return SUGAR_OK;
+  }
   const int smem = r2_smem_bytes(t_max, wp, halo, a.k_pad);
   SUGAR_CHECK_ARG(smem <= 160 * 1024 && a.k_pad <= 320, "res2: tile does not fit LDS (%d bytes)", smem);
   const int mt = (wp + 15) / 16;

@@ -2,8 +2,9 @@
 GPU: the 1024-channel backbone family (reference tdnn16m4g / tdnn26m7g, sugar/models/dynamictdnn.py:942-948) on the HIP
 path, against embeddings of the real reference (tests/golden/round2.npz, oracle/make_golden_round2.py).  These are the
 "1024-channel TDNN convs" BASELINE.json's north_star names: first/last convs 1024 -> 1024 (K = 1024: the 256 x 256
-ping-pong GEMM), catconv 3072 -> 1536, layer1 80 -> 1024 as the tap GEMM.  Res2 width 128 exceeds the fused chain
-kernel's 64-channel tile, so those blocks run the Res2 steps as 7 generic launches (documented fallback).
+ping-pong GEMM), catconv 3072 -> 1536, layer1 80 -> 1024 as the tap GEMM.  Res2 groups of 96 / 128 channels run in
+res2_wide_kernel (the chain in one kernel, weights staged in 32- or 64-channel sub-passes); other widths above 64 fall
+back to 7 generic launches per block.
 """
 import os
 
@@ -74,3 +75,62 @@ def test_1024_channel_persistent_gemm_is_bit_identical_to_one_workgroup_per_tile
     assert torch.isfinite(persistent).all() and torch.equal(persistent, per_tile)
     small = model(wav[:4])
     assert torch.equal(persistent.view(44, 4, 192), small.unsqueeze(0).expand(44, 4, 192))
+
+
+def _row_off(frames):
+    off = [0]
+    for t in frames:
+        off.append(off[-1] + t)
+    return off
+
+
+# 128-channel Res2 groups with 5 taps (32-channel weight sub-passes), with 3 taps (64-channel sub-passes), 96-channel groups
+R2_WIDE_CASES = {"w128k5": (2, [1024, 1024, 1024], [5, 5, 5], 1536), "w128k3": (2, [1024, 1024, 1024], [5, 3, 3], 1536),
+                 "w96": (2, [512, 768, 768], [3, 3, 5], 1536), "w128k1+w64": (2, [768, 1024, 512], [3, 1, 3], 1152)}
+
+
+@pytest.mark.parametrize("name", sorted(R2_WIDE_CASES))
+def test_wide_res2_chain_matches_per_step_path_bf16(name, wide_supernet):
+    """The one-kernel Res2 chain for 65..128-channel groups (res2_wide_kernel) against the 7-launch generic path, same
+    bf16 inputs; ragged utterances including ones cut into time segments.  As for the narrow kernel the two differ by
+    one bf16 rounding per step (the fused chain adds x_j + sp_{j-1} before rounding)."""
+    from sugar_amd import _lib
+    cfg = R2_WIDE_CASES[name]
+    sub = wide_supernet.clone(cfg).set_precision("bf16")
+    wide_supernet.config = None
+    frames = [301, 63, 17, 130, 700, 385, 16]
+    R = sum(frames)
+    feats = synth.normal("res2wide/feats", (R, 80), seed=9).to(torch.bfloat16).to(DEV)
+    row_off = torch.tensor(_row_off(frames), dtype=torch.int32, device=DEV)
+    depth = cfg[0]
+    outs = {}
+    for mode in ("fused", "generic"):
+        with _lib.tuned(generic_res2=int(mode == "generic")):
+            outs[mode] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
+            outs[mode].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
+    for i in range(depth):
+        a, b = outs["fused"][i].float(), outs["generic"][i].float()
+        assert torch.isfinite(a).all()
+        rel = ((a - b).norm() / b.norm()).item()
+        print(name, "block", i, "res2 rel L2 fused vs per-step %.2e" % rel)
+        assert rel < 1.5e-2, (name, i, rel)
+    cos = F.cosine_similarity(outs["fused"][-1].double(), outs["generic"][-1].double(), dim=1)
+    assert cos.min() > 0.9995
+
+
+def test_wide_res2_time_segments_are_bit_identical(wide_supernet):
+    from sugar_amd import _lib
+    cfg = R2_WIDE_CASES["w128k3"]
+    sub = wide_supernet.clone(cfg).set_precision("bf16")
+    wide_supernet.config = None
+    frames = [384, 301, 129, 16, 383, 200]
+    R = sum(frames)
+    feats = synth.normal("res2wideseg/feats", (R, 80), seed=10).to(torch.bfloat16).to(DEV)
+    row_off = torch.tensor(_row_off(frames), dtype=torch.int32, device=DEV)
+    outs = {}
+    for cap in (0, 256, 160):
+        with _lib.tuned(res2_max_t=cap):
+            outs[cap] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(cfg[0])]
+    for cap in (256, 160):
+        for i in range(cfg[0]):
+            assert torch.equal(outs[0][i], outs[cap][i]), (cap, i)
