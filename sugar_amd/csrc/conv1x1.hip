@@ -377,34 +377,37 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
       bn[a.cout + i] = a.shift[i];
     }
   }
-  // DMA sources of the tile being staged (k-tile 0): each wave its rows of both operands, 8 rows (1 KiB) per instruction
-  const bf16* wsrc[WI];
-  const bf16* xsrc[XI];
-  auto point_at = [&](int co_base, int r_base) {
+  // DMA sources: each wave its rows of both operands, 8 rows (1 KiB) per instruction.  Kept as 32-bit element offsets
+  // from uniform bases (launch_split checks that they fit): 64-bit pointers per instruction cost 8 more VGPRs, the
+  // kernel then spilled, and the reloads' vmcnt(0) waits sat between the DMA instructions of the prefetch.
+  unsigned woff[WI], xoff[XI];
 #pragma unroll
-    for (int i = 0; i < WI; ++i) {
-      const int row = wv * (WI * 8) + i * 8 + srow;
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);        // source chunk that belongs at LDS position lane & 7
-      wsrc[i] = a.w + (size_t)(co_base + row) * a.ldw + chunk * 8;
-    }
+  for (int i = 0; i < WI; ++i) {
+    const int row = wv * (WI * 8) + i * 8 + srow;
+    woff[i] = (unsigned)(row * a.ldw + ((lane & 7) ^ ((row >> 1) & 7)) * 8);   // source chunk that belongs at LDS position lane & 7
+  }
+  const bf16* wtile = a.w;                                     // weight rows of the tile being staged
+  auto point_at = [&](int co_base, int r_base) {
+    wtile = a.w + (size_t)co_base * a.ldw;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int row = wv * (XI * 8) + i * 8 + srow;
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      const int xr = min(r_base + row, a.R - 1);              // rows past R: any valid row, masked at the store
-      xsrc[i] = a.x + (size_t)xr * a.ldx + chunk * 8;
+      const int xr = min(r_base + row, a.R - 1);               // rows past R: any valid row, masked at the store
+      xoff[i] = (unsigned)xr * (unsigned)a.ldx + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 8);
     }
   };
   auto stage = [&](int buf, int kt) {
     unsigned char* wbase = smem + buf * STAGE_BYTES + wv * (WI * 8) * 128;
     unsigned char* xbase = smem + buf * STAGE_BYTES + TM * 128 + wv * (XI * 8) * 128;
+    const bf16* wk = wtile + kt * TK;
+    const bf16* xk = a.x + kt * TK;
 #pragma unroll
     for (int i = 0; i < WI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * TK),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
                                        (__attribute__((address_space(3))) void*)(wbase + i * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < XI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + kt * TK),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
                                        (__attribute__((address_space(3))) void*)(xbase + i * 1024), 16, 0, 0);
   };
   auto tile_at = [&](int r, int& co_base, int& r_base) {
@@ -548,6 +551,7 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
   const int n_main = total / n_cu * n_cu, tail = total - n_main;
   const int split = tail == 0 ? 1 : tail * 4 <= n_cu ? 4 : tail * 2 <= n_cu ? 2 : 1;
   if (PP == 1 && n_main >= 2 * n_cu && n_cu % 8 == 0 && (a.K / TK) % 2 == 0 && !a.xmap && a.cout <= 3072 && a.cout % 4 == 0 &&
+      (int64_t)a.R * a.ldx < (1ll << 31) && (int64_t)256 * a.ldw < (1ll << 31) &&
       !tune_get(TUNE_GEMM_NO_PERSIST)) {
     // two rounds or more: one persistent workgroup per CU (stage 1 + 8 x 8 704 bytes of epilogue staging behind it)
     constexpr int psmem = (256 + 256) * 128 + 8 * (16 * 2 * (128 * 2 + 16)) + 2 * 3072 * 4;   // + folded-BN vectors
