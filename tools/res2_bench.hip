@@ -15,6 +15,12 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
   fputc('\n', stderr);
 }
+int device_cu_count(int* n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SUGAR_EHIP;
+  return hipDeviceGetAttribute(n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess ? SUGAR_OK : SUGAR_EHIP;
+}
+int64_t tune_get(int) { return 0; }   // (library tunables: all at their "off" value here)
 }  // namespace sugar
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
