@@ -73,6 +73,36 @@ def gather_results(local, world=None):
     return out
 
 
+class _TrialSnapshot:
+    """The sweep's own view of a trial list: labels / enrolls / tests read ONCE, so that score_trials' index memo (which
+    only trusts VerificationTrials-shaped objects) holds for every subnet whatever container the caller passed."""
+
+    def __init__(self, dataset):
+        self.utterances = dataset.utterances
+        if all(isinstance(getattr(dataset, a, None), list) for a in ("labels", "enrolls", "tests")):
+            self.labels, self.enrolls, self.tests = list(dataset.labels), list(dataset.enrolls), list(dataset.tests)
+        else:
+            rows = [(tr["label"], tr["enroll"], tr["test"]) for tr in dataset]
+            self.labels = [r[0] for r in rows]
+            self.enrolls = [r[1] for r in rows]
+            self.tests = [r[2] for r in rows]
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, i):
+        return {"label": self.labels[i], "enroll": self.enrolls[i], "test": self.tests[i]}
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class _LoaderView:
+    def __init__(self, loader, dataset):
+        self.dataset, self.batch_size = dataset, loader.batch_size
+        self.num_workers = getattr(loader, "num_workers", 0)
+
+
 def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transform=None, device="cuda:0",
                      precision="bf16", norm=True, p_target=0.05, prefetch=True, rank=None, world=None, gather=True,
                      on_result=None):
@@ -101,6 +131,7 @@ def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transfor
     fb = transform if transform is not None else LogMelFbanks()
     # the evaluation list is walked and staged on the GPU once for all subnets
     packed = PackedUtterances(veri_loader.dataset.utterances, dev, batch_size=max(1, int(veri_loader.batch_size)))
+    veri_loader = _LoaderView(veri_loader, _TrialSnapshot(veri_loader.dataset))     # trial list parsed once
     results = {}
     pool = ThreadPoolExecutor(max_workers=1) if prefetch and len(mine) > 1 else None
     try:
