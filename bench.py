@@ -131,11 +131,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
+    # SUGAR_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share the cards,
+    # the embeddings are exchanged through gloo); the driver's runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("SUGAR_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and local >= n_dev:
+        sys.exit("bench.py: rank %d has no GPU of its own (%d visible)" % (rank, n_dev))
+    local = local % max(1, n_dev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg, B, L, family = WORKLOADS[args.workload]
     config = getattr(layout, cfg) if isinstance(cfg, str) else cfg
@@ -153,6 +163,12 @@ def main():
 
     gathered = [torch.empty(world * B, 192, device=dev) for _ in range(2)] if world > 1 else None
 
+    def all_gather(i, emb):
+        if backend == "nccl":
+            return dist.all_gather_into_tensor(gathered[i & 1], emb, async_op=True)
+        torch.cuda.current_stream().synchronize()          # gloo reads the tensor from the host side
+        return dist.all_gather(list(gathered[i & 1].view(world, B, 192).unbind(0)), emb, async_op=True)
+
     lanes = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))]
 
     def step(i):
@@ -160,7 +176,7 @@ def main():
         with torch.cuda.stream(lanes[i % len(lanes)]):
             emb = model(wav, normalize=True)
             if world > 1:
-                return dist.all_gather_into_tensor(gathered[i & 1], emb, async_op=True)
+                return all_gather(i, emb)
         return None
 
     def sync_all():
@@ -206,7 +222,7 @@ def main():
             with torch.cuda.stream(lanes2[i & 1]):
                 emb = model(wav, normalize=True)
                 if world > 1:
-                    return dist.all_gather_into_tensor(gathered[i & 1], emb, async_op=True)
+                    return all_gather(i, emb)
             return None
 
         for i in range(2):
@@ -277,7 +293,7 @@ def main():
                                    "waveform -> fbank -> TDNN -> L2-normalised 192-d embedding"
                                    % (args.workload, layout.config_name(config), B),
                        "per_gpu_batch": B, "global_batch": world * B, "frames_per_utt": T,
-                       "parallelism": "utterance-sharded x%d, all-gather of embeddings" % world,
+                       "parallelism": "utterance-sharded x%d, all-gather of embeddings (%s)" % (world, backend),
                        "streams": len(lanes), "preheat_steps": args.preheat,
                        "weights": "deterministic synthetic (sugar_amd/synth.py)"},
             "roofline": {"kernel": "%s catconv launch [%d frames x K %d -> %d]"
