@@ -191,8 +191,9 @@ int gemm_taps_slack(const ConvLayer& L, int B, int64_t R);   // rows that close 
 int launch_pad_rows(const ConvLayer& L, const void* d_x, void* d_xpad, const int32_t* d_row_off, int B, int64_t R, int t_max,
                     hipStream_t s);
 int64_t gemm_taps_orow_ints(const ConvLayer& L, int B, int64_t R);   // int32 entries of the output-row map d_orow
+// orow_ready: d_orow already holds the map (the fused front-end wrote it); otherwise a small kernel builds it first
 int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, void* d_y, int ldy, const int32_t* d_row_off,
-                     int B, int64_t R, int t_max, hipStream_t s);
+                     int B, int64_t R, int t_max, hipStream_t s, bool orow_ready = false);
 
 // Pack a reference-layout conv weight [cout][cin][k] (host f32) into ConvLayer storage with an internal channel
 // permutation / padding: out_map[o] = packed output row of reference channel o, in_map[i] = packed input
@@ -213,7 +214,7 @@ int64_t fbank_scratch_floats(int B, int64_t R);
 // halo + t, halo zero rows either side of every utterance, `slack` more after the last one), written directly
 int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
                  int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s, int halo = 0,
-                 int slack = 0);
+                 int slack = 0, int32_t* d_orow = nullptr, int64_t orow_n = 0);   // d_orow: also the layer1 GEMM's output-row map
 
 // ---- SE / pooling / tail (se_pool.hip) ----------------------------------------------------------
 struct SELayer {            // device, f32, transposed for coalesced reads

@@ -892,7 +892,7 @@ int64_t gemm_taps_orow_ints(const ConvLayer& L, int B, int64_t R) {
 }
 
 int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, void* d_y, int ldy, const int32_t* d_row_off,
-                     int B, int64_t R, int t_max, hipStream_t s) {
+                     int B, int64_t R, int t_max, hipStream_t s, bool orow_ready) {
   const int halo = (L.ktaps - 1) / 2, C = L.cin_p;
   SUGAR_CHECK_ARG(((uintptr_t)d_xpad & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && ldy % 8 == 0, "gemm_taps: unaligned buffers");
   Gemm1x1Args a;
@@ -904,9 +904,11 @@ int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, vo
     // large inputs: weights in registers, one pass over the padded rows (the tile kernel below re-streams the weight
     // panel and the activation rows from L2 for each of its 128 x 128 tiles: 554 MB of DMA for 91 MB of tensors)
     const int64_t n_total = gemm_taps_orow_ints(L, B, R);
-    const unsigned gx = (unsigned)(ceil_div(t_max + 2 * halo + WR_TN, 256) < 8 ? ceil_div(t_max + 2 * halo + WR_TN, 256) : 8);
-    hipLaunchKernelGGL(build_orow_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, d_row_off, halo, (int)n_total, d_orow);
-    SUGAR_LAUNCH_CHECK();
+    if (!orow_ready) {
+      const unsigned gx = (unsigned)(ceil_div(t_max + 2 * halo + WR_TN, 256) < 8 ? ceil_div(t_max + 2 * halo + WR_TN, 256) : 8);
+      hipLaunchKernelGGL(build_orow_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, d_row_off, halo, (int)n_total, d_orow);
+      SUGAR_LAUNCH_CHECK();
+    }
     a.R = (int)(R + (int64_t)2 * halo * B);           // GEMM rows = padded rows
     a.orow = d_orow;
     a.wfrag = (const bf16*)L.wfrag;

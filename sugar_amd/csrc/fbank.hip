@@ -346,11 +346,22 @@ constexpr int NORM_CACHE = 40;  // rows per lane kept in registers
 // Output rows: utterance b's frame t at row row_off[b] + t, or -- halo > 0, the layout the layer1 tap GEMM reads
 // (conv1x1.hip, launch_pad_rows) -- at row_off[b] + 2 halo b + halo + t with the halo rows (and, behind the last
 // utterance, `slack` more rows) zeroed here.
+// orow (optional, orow_n entries): the layer1 GEMM's output-row map of that padded row space (conv1x1.hip,
+// build_orow_kernel): frame t of this part (t_lo <= t < t_hi) -> row_off[b] + t, halo / slack rows -> -1.
 template <typename T>
 __device__ __forceinline__ T* padded_rows(T* feats, int s, int n, int b, int n_utts, int halo, int slack, bool first_part,
-                                          bool last_part) {
+                                          bool last_part, int32_t* orow, int orow_n, int t_lo, int t_hi) {
   if (!halo) return feats + (size_t)s * NMEL;
   T* base = feats + ((size_t)s + (size_t)2 * halo * b + halo) * NMEL;
+  if (orow) {
+    // GEMM row q0 + t reads the K vector that STARTS at padded row q0 + t (taps t - halo .. t + halo of frame t)
+    const int q0 = s + 2 * halo * b;
+    if (last_part) {
+      const int after = 2 * halo + (b == n_utts - 1 ? slack : 0);
+      for (int i = threadIdx.x; i < after && q0 + n + i < orow_n; i += blockDim.x) orow[q0 + n + i] = -1;
+    }
+    for (int t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) orow[q0 + t] = s + t;
+  }
   if (first_part)
     for (int i = threadIdx.x; i < halo * NMEL; i += blockDim.x) (base - halo * NMEL)[i] = from_f32<T>(0.f);
   if (last_part) {
@@ -363,7 +374,8 @@ __device__ __forceinline__ T* padded_rows(T* feats, int s, int n, int b, int n_u
 template <typename T>
 __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float* __restrict__ logmel,
                                                                      const int32_t* __restrict__ row_off,
-                                                                     T* __restrict__ feats, int halo, int slack) {
+                                                                     T* __restrict__ feats, int halo, int slack,
+                                                                     int32_t* __restrict__ orow, int orow_n) {
   __shared__ float red[NORM_LANES][NMEL];
   const int b = blockIdx.x;
   const int s = row_off[b], n = row_off[b + 1] - s;
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_kernel(const float*
   for (int i = 0; i < NORM_LANES; ++i) var += red[i][m];
   var /= (float)n;                                     // biased, as InstanceNorm1d
   const float inv = 1.0f / sqrtf(var + 1e-5f);
-  T* __restrict__ dst = padded_rows(feats, s, n, b, (int)gridDim.x, halo, slack, true, true) + m;
+  T* __restrict__ dst = padded_rows(feats, s, n, b, (int)gridDim.x, halo, slack, true, true, orow, orow_n, 0, n) + m;
 #pragma unroll
   for (int i = 0; i < NORM_CACHE; ++i) {
     const int r = rl + NORM_LANES * i;
@@ -473,7 +485,8 @@ template <typename T>
 __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_apply_kernel(const float* __restrict__ logmel,
                                                                            const int32_t* __restrict__ row_off,
                                                                            const float* __restrict__ part,
-                                                                           T* __restrict__ feats, int halo, int slack) {
+                                                                           T* __restrict__ feats, int halo, int slack,
+                                                                           int32_t* __restrict__ orow, int orow_n) {
   const int b = blockIdx.y, c = blockIdx.x;
   const int s = row_off[b], nu = row_off[b + 1] - s;
   const int r0 = c * NORM_CHUNK;
@@ -503,7 +516,8 @@ __global__ __launch_bounds__(NMEL* NORM_LANES) void instnorm_apply_kernel(const 
     var = (float)(m2 / (double)nu);                    // biased, as InstanceNorm1d
   }
   const float inv = 1.0f / sqrtf(var + 1e-5f);
-  T* __restrict__ dst = padded_rows(feats, s, nu, b, (int)gridDim.y, halo, slack, c == 0, r0 + NORM_CHUNK >= nu) +
+  T* __restrict__ dst = padded_rows(feats, s, nu, b, (int)gridDim.y, halo, slack, c == 0, r0 + NORM_CHUNK >= nu, orow, orow_n,
+                                    r0, min(nu, r0 + NORM_CHUNK)) +
                         (size_t)r0 * NMEL + m;
 #pragma unroll
   for (int i = 0; i < NORM_CACHE; ++i) {
@@ -521,7 +535,9 @@ int fbank_init() {
 int64_t fbank_scratch_floats(int B, int64_t R) { return R * NMEL + (R / NORM_CHUNK + B + 1) * (2 * NMEL); }
 
 int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len, const int32_t* d_row_off,
-                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s, int halo, int slack) {
+                 int B, int64_t R, int t_max, float* d_logmel, void* d_feats, int dtype, hipStream_t s, int halo, int slack,
+                 int32_t* d_orow, int64_t orow_n) {
+  SUGAR_CHECK_ARG(!d_orow || (halo > 0 && orow_n > 0 && orow_n < (1ll << 31)), "fbank: output-row map without a padded layout");
   SUGAR_CHECK_ARG(d_wav && d_wav_off && d_wav_len && d_row_off && d_logmel && d_feats, "fbank: null pointer");
   SUGAR_CHECK_ARG(B > 0 && B <= 65535 && t_max > 0 && R >= t_max, "fbank: bad batch %d / t_max %d / R %lld", B, t_max, (long long)R);
   SUGAR_CHECK_ARG(dtype == SUGAR_F32 || dtype == SUGAR_BF16, "fbank: bad dtype %d", dtype);
@@ -539,19 +555,19 @@ int launch_fbank(const float* d_wav, const int64_t* d_wav_off, const int32_t* d_
     SUGAR_LAUNCH_CHECK();
     if (dtype == SUGAR_F32)
       hipLaunchKernelGGL(instnorm_apply_kernel<float>, grid, dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off, part,
-                         (float*)d_feats, halo, slack);
+                         (float*)d_feats, halo, slack, d_orow, (int)orow_n);
     else
       hipLaunchKernelGGL(instnorm_apply_kernel<bf16>, grid, dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off, part,
-                         (bf16*)d_feats, halo, slack);
+                         (bf16*)d_feats, halo, slack, d_orow, (int)orow_n);
     SUGAR_LAUNCH_CHECK();
     return SUGAR_OK;
   }
   if (dtype == SUGAR_F32)
     hipLaunchKernelGGL(instnorm_kernel<float>, dim3((unsigned)B), dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off,
-                       (float*)d_feats, halo, slack);
+                       (float*)d_feats, halo, slack, d_orow, (int)orow_n);
   else
     hipLaunchKernelGGL(instnorm_kernel<bf16>, dim3((unsigned)B), dim3(NMEL * NORM_LANES), 0, s, d_logmel, d_row_off,
-                       (bf16*)d_feats, halo, slack);
+                       (bf16*)d_feats, halo, slack, d_orow, (int)orow_n);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }

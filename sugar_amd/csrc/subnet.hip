@@ -411,7 +411,8 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
     Prof p(SUGAR_STAGE_LAYER1, s);
     if (layer1_as_tap_gemm(n)) {
       if (feats && (rc = launch_pad_rows(n->layer1, feats, w.featp, row_off, B, R, t_max, s))) return rc;
-      rc = launch_gemm_taps(n->layer1, w.featp, w.orow, w.S, n->c0p, row_off, B, R, t_max, s);
+      // feats == nullptr: the fused front-end has written the padded layout AND its output-row map
+      rc = launch_gemm_taps(n->layer1, w.featp, w.orow, w.S, n->c0p, row_off, B, R, t_max, s, feats == nullptr);
     } else {
       SUGAR_CHECK_ARG(feats, "forward: features missing");
       rc = conv(n->layer1, io);
@@ -682,7 +683,8 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
   {
     Prof p(SUGAR_STAGE_FBANK, s);
     if ((rc = launch_fbank(d_wav, d_wav_off, d_wav_len, d_row_off, B, R, t_max, w.logmel, padded ? w.featp : w.feats,
-                           net->dtype, s, halo, padded ? gemm_taps_slack(net->layer1, B, R) : 0)))
+                           net->dtype, s, halo, padded ? gemm_taps_slack(net->layer1, B, R) : 0, padded ? w.orow : nullptr,
+                           padded ? gemm_taps_orow_ints(net->layer1, B, R) : 0)))
       return rc;
   }
   return tdnn_forward(net, padded ? nullptr : w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
