@@ -950,6 +950,8 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       const int64_t wreg_min_r = tune_get(TUNE_GEMM_WREG_MIN_R);
       // (K = 256 .. 448 instantiations were measured on the NAS sweep, tools/sweep_bench.py: 31.5-32.7 vs 30.1-31.0 ms
       // per subnet, so the narrower convs stay on the tile kernel)
+      // (the persistent 256 x 256 kernel on these shapes: 0.208 / 0.192 ms per step for first / last conv against
+      // 0.170 / 0.158 here -- 8 k-tiles per tile leave its epilogue a third of the tile)
       if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) {
         a.wfrag = (const bf16*)L.wfrag;
         return launch_wreg<8, 2, 4>(a, s);
