@@ -11,7 +11,7 @@ the only exchange step is the all-gather of the [256, 192] embeddings of each st
 asynchronously and completed inside the timed region.
 
 Rank 0 prints ONE JSON line (see the driver contract); it carries
-  roofline     : the dominant kernel = the catconv implicit-GEMM launch (49 % of the MACs): algorithmic FLOPs per
+  roofline     : the dominant kernel = the catconv GEMM launch (49 % of the MACs): algorithmic FLOPs per
                  launch / its average duration, measured live with hipEvents on the launch stream over the timed steps
   cpu_baseline : the oracle (oracle/ref_cpu.py, a CPU restatement of the reference path) timed on the host cores
                  on a bounded sample (8 x 3 s batches for ~10 s), rank 0 at N = 1 only
@@ -297,7 +297,7 @@ def main():
                        "streams": len(lanes), "preheat_steps": args.preheat,
                        "weights": "deterministic synthetic (sugar_amd/synth.py)"},
             "roofline": {"kernel": "%s catconv launch [%d frames x K %d -> %d]"
-                                   % ("gemm1x1_split_kernel<2> (256x256x64 LDS-DMA MFMA GEMM, split-tail grid)" if args.precision == "bf16"
+                                   % ("gemm1x1_persist_kernel (256x256x64 LDS-DMA MFMA GEMM, ping-pong schedule, persistent split-tail grid)" if args.precision == "bf16"
                                       else "conv_gemm_kernel<float,128,128>", R, depth * ch[0], ccat),
                          "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None,
