@@ -123,6 +123,14 @@ __device__ __forceinline__ float dpp_row_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
+// tanh of the pooling.linear1 epilogue when the result is stored as bf16: 1 - 2 / (2^(2 x log2 e) + 1) with the hardware
+// exp2 / rcp (absolute error ~1e-7, far below the bf16 rounding that follows; exact limits +-1 for large |x|).  tanhf is
+// ~30 VALU instructions per element, and pooling.linear1's lone wave per SIMD spent a third of every tile in it.
+__device__ __forceinline__ float tanh_bf16_epilogue(float x) {
+  const float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
 template <typename T>

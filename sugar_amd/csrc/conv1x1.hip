@@ -290,7 +290,7 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
         v = v * sc + sh;
         if (tanh_) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = tanh_bf16_epilogue(v[e]);
         }
         const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         *(bf16x4*)(ep + (nn * 16 + fr) * EPI_STRIDE + col * 2) = o;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
           v = v * sc + sh;
           if (tanh_) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = tanh_bf16_epilogue(v[e]);
           }
           const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
           *(bf16x4*)(ep + (nn * 16 + fr) * EPI_STRIDE + col * 2) = o;
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
         v = v * scp[m] + shp[m];
         if (tanh_) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = tanh_bf16_epilogue(v[e]);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[4 * m + e] = (bf16)v[e];

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
         }
         if (tanh_) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? tanh_bf16_epilogue(v[e]) : tanhf(v[e]);   // (bf16: as conv1x1.hip)
         }
         if constexpr (DT<T>::id == SUGAR_F32) {
           *(f32x4*)(y + (size_t)r * a.ldy + co) = v;
