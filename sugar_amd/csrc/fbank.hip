@@ -333,8 +333,9 @@ __global__ __launch_bounds__(256, 4) void fbank_fft_kernel(const float* __restri
       // straight to the log-mel rows (256 + 64 contiguous bytes per frame): a staging tile in LDS cost 10 KiB per
       // workgroup and, with it, the fourth workgroup per CU
       float* __restrict__ dst = logmel + (size_t)(row0 + t0 + f) * NMEL;
-      dst[mel0] = logf(s + 1e-6f);
-      if ((j & 3) == 0) dst[mel1] = logf(s2 + 1e-6f);
+      // log = log2 * ln 2 with the hardware log2 (arguments >= 1e-6: no denormals; logf's range handling is ~20 VALU)
+      dst[mel0] = __builtin_amdgcn_logf(s + 1e-6f) * 0.6931471805599453f;
+      if ((j & 3) == 0) dst[mel1] = __builtin_amdgcn_logf(s2 + 1e-6f) * 0.6931471805599453f;
     }
     __builtin_amdgcn_wave_barrier();
   }
