@@ -32,6 +32,7 @@ WORKLOADS = {
     # 1024-channel tdnn16m4g (sugar/models/dynamictdnn.py:942-944), the "1024-channel convs" of north_star
     "base256": ("BASE", 256, 48000, "tdnn8m2g"),
     "largest256": ("LARGEST", 256, 48000, "tdnn8m2g"),
+    "base64": ("BASE", 64, 48000, "tdnn8m2g"),       # diagnostic: every activation tensor fits the 256 MB Infinity Cache
     "wide256": ((3, [1024] * 4, [5] * 4, 1536), 256, 48000, "tdnn16m4g"),
 }
 SUPERNETS = {"tdnn8m2g": (80, 192, 4, 512, 5, 1536), "tdnn16m4g": (80, 192, 3, 1024, 5, 1536)}   # supernet_shapes arguments

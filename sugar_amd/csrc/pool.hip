@@ -46,7 +46,8 @@ struct PoolMma<float> {
 };
 
 constexpr int PT = 32;     // frames per tile
-constexpr int PC = 256;    // channels per workgroup
+constexpr int NT = 512;    // threads per workgroup
+constexpr int PC = NT / 2;    // channels per workgroup (32 per wave)
 constexpr int BOTT = 128;
 constexpr int POOL_SEG = 1024;   // frames per time segment (multiple of PT)
 
@@ -60,7 +61,7 @@ __device__ __forceinline__ int pool_xcd_remap(int bid, int nwg) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel(const T* __restrict__ a, int lda, const T* __restrict__ h,
+__global__ __launch_bounds__(NT, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel(const T* __restrict__ a, int lda, const T* __restrict__ h,
                                                          int ldh, const T* __restrict__ w2, int ccat_p,
                                                          const int32_t* __restrict__ row_off,
                                                          float* __restrict__ pooled, float* __restrict__ part) {
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
   constexpr int H_CH = PC / E;                   // chunks per h row slab      (32 / 64)
   constexpr int A_BYTES = PT * BOTT * (int)sizeof(T);
   constexpr int H_BYTES = PT * PC * (int)sizeof(T);
-  constexpr int A_PER = PT * A_CH / 512;         // chunks each thread stages  (1 / 2)
-  constexpr int H_PER = PT * H_CH / 512;         //                            (2 / 4)
+  constexpr int A_PER = PT * A_CH / NT;         // chunks each thread stages  (1 / 2)
+  constexpr int H_PER = PT * H_CH / NT;         //                            (2 / 4)
   typedef typename PoolMma<T>::Frag Frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x (a tile | h tile)
 
@@ -95,71 +96,98 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
   Frag wf[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) wf[g] = *(const Frag*)(w2 + (size_t)co * BOTT + (2 * g + fh) * E);
+  // the weights are in registers from here on: without this hipcc carries their loads' vmcnt bookkeeping into the tile
+  // loop and makes the MFMAs wait for the tile prefetch issued at the top of the same iteration
+#pragma unroll
+  for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(wf[g]));
 
-  u32x4 areg[A_PER], hreg[H_PER];
-  auto load_tile = [&](int t0) {
+  // two tiles of global loads in flight per thread (register sets q = 0 / 1; 96 KiB per CU on their way instead of
+  // 48).  Measured with the two changes above in one job, 256 x 3 s: 0.0672 -> 0.0650 ms.  Knock-outs of the same
+  // build: no MFMAs 0.0485, no softmax arithmetic 0.0492, no LDS staging 0.0519, no loads 0.0577,
+  // neither arithmetic nor loads 0.0368 -- the parts add up, the 8 lock-stepped waves of a workgroup overlap little
+  u32x4 areg[2][A_PER], hreg[2][H_PER];
+  auto load_tile = [&](auto qt, int t0) {
+    constexpr int q = decltype(qt)::value;
+    // past the last tile (uniform): every row index collapses to the segment's first row -- the same three load
+    // instructions are issued (L2 hits on 0.5 KiB), so the vmcnt arithmetic of store_tile below is the same on every
+    // path; with a branch around the loads hipcc waits for ALL outstanding loads there, the newest tile's included
+    const int rmax = t0 < n ? n - 1 : 0;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
-      // unconditional load from a clamped row; the zero-select happens in store_tile, one tile later, so nothing
-      // waits on the load here and it stays in flight under this tile's MFMAs and exps
-      areg[i] = *(const u32x4*)(a + (size_t)(s + min(t0 + row, n - 1)) * lda + ch * E);
+      const int idx = tid + i * NT, row = idx / A_CH, ch = idx % A_CH;
+      // unconditional load from a clamped row; the zero-select happens in store_tile, a tile or two later, so nothing
+      // waits on the load here and it stays in flight under the MFMAs and exps of the tiles before
+      areg[q][i] = *(const u32x4*)(a + (size_t)(s + min(t0 + row, rmax)) * lda + ch * E);
     }
 #pragma unroll
     for (int i = 0; i < H_PER; ++i) {
-      const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
+      const int idx = tid + i * NT, row = idx / H_CH, ch = idx % H_CH;
       const int cc = min(c_base + ch * E, ccat_p - E);
-      hreg[i] = *(const u32x4*)(h + (size_t)(s + min(t0 + row, n - 1)) * ldh + cc);
+      hreg[q][i] = *(const u32x4*)(h + (size_t)(s + min(t0 + row, rmax)) * ldh + cc);
     }
   };
-  auto store_tile = [&](int buf, int t0) {
+  auto store_tile = [&](auto qt, int buf, int t0) {
+    constexpr int q = decltype(qt)::value;
     unsigned char* ab = smem + buf * (A_BYTES + H_BYTES);
     unsigned char* hb = ab + A_BYTES;
     const bool full = t0 + PT <= n && c_base + PC <= ccat_p;      // (uniform) no row or channel of the tile to zero
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      const int idx = tid + i * 512, row = idx / A_CH, ch = idx % A_CH;
-      *(u32x4*)(ab + row * (A_CH * 16) + ((ch ^ (row & 15)) << 4)) = full || t0 + row < n ? areg[i] : (u32x4){0u, 0u, 0u, 0u};
+      const int idx = tid + i * NT, row = idx / A_CH, ch = idx % A_CH;
+      *(u32x4*)(ab + row * (A_CH * 16) + ((ch ^ (row & 15)) << 4)) = full || t0 + row < n ? areg[q][i] : (u32x4){0u, 0u, 0u, 0u};
     }
     if (full) {
 #pragma unroll
-      for (int i = 0; i < H_PER; ++i) *(u32x4*)(hb + (tid + i * 512) * 16) = hreg[i];
+      for (int i = 0; i < H_PER; ++i) *(u32x4*)(hb + (tid + i * NT) * 16) = hreg[q][i];
     } else {
 #pragma unroll
       for (int i = 0; i < H_PER; ++i) {
-        const int idx = tid + i * 512, row = idx / H_CH, ch = idx % H_CH;
+        const int idx = tid + i * NT, row = idx / H_CH, ch = idx % H_CH;
         const bool ok = t0 + row < n && c_base + ch * E < ccat_p;
-        *(u32x4*)(hb + idx * 16) = ok ? hreg[i] : (u32x4){0u, 0u, 0u, 0u};        // plain [row][channel] image
+        *(u32x4*)(hb + idx * 16) = ok ? hreg[q][i] : (u32x4){0u, 0u, 0u, 0u};        // plain [row][channel] image
       }
     }
   };
 
   float m = -1e30f, l = 0.f, s1 = 0.f, s2 = 0.f;
   const int ntiles = (n + PT - 1) / PT;
-  load_tile(0);
-  store_tile(0, 0);
+  typedef std::integral_constant<int, 0> Q0;
+  typedef std::integral_constant<int, 1> Q1;
+  load_tile(Q0{}, 0);
+  load_tile(Q1{}, PT);
+  store_tile(Q0{}, 0, 0);
   __syncthreads();
-  for (int it = 0; it < ntiles; ++it) {
+  // tile `it` is computed from LDS buffer it & 1; its register set (it & 1) is free and takes tile it + 2, while the
+  // other set holds tile it + 1, requested one iteration ago and staged into the other buffer at the end of this one
+  auto step = [&](auto qt, int it) {
+    constexpr int q = decltype(qt)::value;
     const int t0 = it * PT;
-    const bool more = it + 1 < ntiles;
-    if (more) load_tile(t0 + PT);
+    load_tile(std::integral_constant<int, q>{}, t0 + 2 * PT);
     const unsigned char* ab = smem + (it & 1) * (A_BYTES + H_BYTES);
     const T* hs = (const T*)(ab + A_BYTES);
+    const T* hl = hs + (4 * fh) * PC + wv * 32 + fr;    // frame e of this lane: hl[((e & 3) + 8 * (e >> 2)) * PC]
     // logits tile [32 frames][32 channels]
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    constexpr int FB = 4;                           // a-fragments requested ahead of the MFMAs that consume them
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int ch = 2 * g + fh;
-      const Frag af = *(const Frag*)(ab + fr * (A_CH * 16) + ((ch ^ (fr & 15)) << 4));
-      PoolMma<T>::mma(acc, af, wf[g]);
+    for (int g0 = 0; g0 < NG; g0 += FB) {
+      Frag af[FB];
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        const int ch = 2 * (g0 + j) + fh;
+        af[j] = *(const Frag*)(ab + fr * (A_CH * 16) + ((ch ^ (fr & 15)) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);            // (hipcc otherwise sinks every read to right before its MFMA)
+#pragma unroll
+      for (int j = 0; j < FB; ++j) PoolMma<T>::mma(acc, af[j], wf[g0 + j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // online softmax over this tile's 16 frames of the lane's channel, in the exp2 domain (v_exp_f32 is 2^x): m is the
     // running maximum of logit * log2(e).  Only the utterance's last tile can hold frames past n: the row masks are
     // compiled into that tile's copy of the body alone (the loop was VALU-issue-bound: ~300 VALU per tile and wave,
     // a third of them row tests, selects and LDS address arithmetic).
-    const T* hl = hs + (4 * fh) * PC + wv * 32 + fr;    // frame e of this lane: hl[((e & 3) + 8 * (e >> 2)) * PC]
     auto body = [&](auto last_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
       constexpr float LOG2E = 1.4426950408889634f;
@@ -188,26 +216,28 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 4 : 2) void pool_stats_kernel
     };
     if (t0 + PT <= n) body(std::false_type{});
     else body(std::true_type{});
-    if (more) store_tile((it + 1) & 1, t0 + PT);
+    if (it + 1 < ntiles) store_tile(std::integral_constant<int, q ^ 1>{}, (it + 1) & 1, t0 + PT);
     __syncthreads();
+  };
+  for (int it = 0; it < ntiles; it += 2) {
+    step(Q0{}, it);
+    if (it + 1 < ntiles) step(Q1{}, it + 1);
   }
   // merge the two half-waves (same channel, disjoint frames)
   const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), s12 = __shfl_xor(s1, 32), s22 = __shfl_xor(s2, 32);
   const float M = fmaxf(m, m2);                    // (maxima in the exp2 domain: logit * log2(e))
   const float f1 = __builtin_amdgcn_exp2f(m - M), f2 = __builtin_amdgcn_exp2f(m2 - M);
-  l = l * f1 + l2 * f2;
-  s1 = s1 * f1 + s12 * f2;
-  s2 = s2 * f1 + s22 * f2;
+  const float lt = l * f1 + l2 * f2, s1t = s1 * f1 + s12 * f2, s2t = s2 * f1 + s22 * f2;
   if (n_utt > POOL_SEG) {                          // one of several segments: leave the state to pool_merge_kernel
     if (fh == 0 && co_ok) {
       float* p = part + (size_t)(pool_slot(row_off, b) + blockIdx.z) * 4 * ccat_p + co;
-      p[0] = M; p[ccat_p] = l; p[2 * ccat_p] = s1; p[3 * ccat_p] = s2;
+      p[0] = M; p[ccat_p] = lt; p[2 * ccat_p] = s1t; p[3 * ccat_p] = s2t;
     }
     return;
   }
   if (fh == 0 && co_ok) {
-    const float mean = s1 / l;
-    const float var = s2 / l - mean * mean;
+    const float mean = s1t / lt;
+    const float var = s2t / lt - mean * mean;
     pooled[(size_t)b * 2 * ccat_p + co] = mean;
     pooled[(size_t)b * 2 * ccat_p + ccat_p + co] = sqrtf(fmaxf(var, 1e-9f));
   }
@@ -243,7 +273,7 @@ int launch_t(const PoolLayer& P, const void* d_a, int lda, const void* d_h, int 
   static OptInMask opted{0};
   if (int rc = lds_opt_in((const void*)pool_stats_kernel<T>, smem, &opted)) return rc;
   const dim3 grid((unsigned)ceil_div(P.ccat_p, PC), (unsigned)B, (unsigned)ceil_div(t_max, POOL_SEG));
-  hipLaunchKernelGGL(pool_stats_kernel<T>, grid, dim3(512), smem, s, (const T*)d_a, lda, (const T*)d_h, ldh,
+  hipLaunchKernelGGL(pool_stats_kernel<T>, grid, dim3(NT), smem, s, (const T*)d_a, lda, (const T*)d_h, ldh,
                      (const T*)P.w2, P.ccat_p, d_row_off, d_pooled, d_part);
   SUGAR_LAUNCH_CHECK();
   if (t_max > POOL_SEG) {
