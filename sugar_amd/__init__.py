@@ -6,6 +6,7 @@ and its checkpoint format; all device work is hand-written gfx950 HIP behind the
 """
 from .dynamictdnn import (DynamicTDNN, TDNNPath, TDNNSubnet, ecapa_tdnn, specfic_tdnn, tdnn8m2g, tdnn14m4g,
                           tdnn16m4g, tdnn26m7g)
+from .graphs import GraphedEmbedder
 from .latency import TDNNLatency, latency
 from .metrics import calculate_eer, calculate_mindcf
 from .models import SpeakerModel, WrappedModel, batch_forward, bn_state_dict, checkpoint2backbone, veri_validate
@@ -20,4 +21,4 @@ __all__ = ["DynamicTDNN", "TDNNPath", "TDNNSubnet", "ecapa_tdnn", "specfic_tdnn"
            "calculate_score", "score_trials", "LogMelFbanks", "PreEmphasis", "extract_vectors", "veri_validate", "batch_forward",
            "calculate_eer", "calculate_mindcf", "score_cohorts", "asnorm", "snorm", "TDNNLatency", "latency", "evaluate_subnets",
            "shard_configs", "gather_results", "PackedUtterances", "VectorTable",
-           "ArchCoder", "config2d", "AccuracyPredictor", "MinimizeError", "GPULatencyConstraint", "ea_solve"]
+           "ArchCoder", "config2d", "AccuracyPredictor", "MinimizeError", "GPULatencyConstraint", "ea_solve", "GraphedEmbedder"]

@@ -555,6 +555,19 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   {                                                      // parity tests: segment utterances the kernel could hold whole
     const int v = (int)tune_get(TUNE_RES2_MAX_T);
     if (v >= 128 && v <= R2_MAX_T) a.max_t = v & ~15;
+    else if (v == 0) {
+      // Few utterances: one workgroup per utterance leaves most CUs idle (64 x 3 s: a quarter of the chip, and the
+      // chain took as long as at 256 x 3 s).  Cut the utterances into time segments until the grid covers the chip;
+      // every segment recomputes 7 halo frames of context per side, outputs are bit-identical (segment tests).
+      int n_cu = 0;
+      if (int rc = device_cu_count(&n_cu)) return rc;
+      if (B < n_cu) {
+        const int want = (int)ceil_div(n_cu, B);
+        int mt = (int)round_up(round_up(ceil_div(t_max, want), 16) + 2 * R2_STEPS * halo, 16);
+        mt = mt < 128 ? 128 : mt;
+        if (mt < a.max_t && mt < t_max) a.max_t = mt;
+      }
+    }
   }
   a.seg_inner = (a.max_t - 2 * R2_STEPS * halo) & ~15;
   if (a.seg_inner < 16) {                                // override too small for this halo: ignore it
@@ -582,7 +595,7 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
     SUGAR_LAUNCH_CHECK();
     return SUGAR_OK;
   }
-  const int smem = r2_smem_bytes(t_max, wp, halo, a.k_pad);
+  const int smem = r2_smem_bytes(t_max < a.max_t ? t_max : a.max_t, wp, halo, a.k_pad);   // (a segment holds <= max_t frames)
   SUGAR_CHECK_ARG(smem <= 160 * 1024 && a.k_pad <= 320, "res2: tile does not fit LDS (%d bytes)", smem);
   const int mt = (wp + 15) / 16;
   const bool w3 = a.k_pad <= 192;

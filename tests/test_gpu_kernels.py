@@ -444,10 +444,10 @@ def test_res2_time_segments_are_bit_identical(name, meta, supernet):
     row_off = torch.tensor(_row_off(frames), dtype=torch.int32, device=DEV)
     depth = cfg[0]
     outs = {}
-    for cap in (None, "256", "160"):
-        with _lib.tuned(res2_max_t=int(cap or 0)):
+    for cap in (None, "256", "160", "auto"):          # None: whole utterances (384 = the kernel's capacity); auto: the
+        with _lib.tuned(res2_max_t={None: 384, "auto": 0}.get(cap) if cap in (None, "auto") else int(cap)):   # few-utterance rule
             outs[cap] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
             outs[cap].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
-    for cap in ("256", "160"):
+    for cap in ("256", "160", "auto"):
         for i in range(depth + 1):
             assert torch.equal(outs[None][i], outs[cap][i]), (name, cap, i)

@@ -128,9 +128,9 @@ def test_wide_res2_time_segments_are_bit_identical(wide_supernet):
     feats = synth.normal("res2wideseg/feats", (R, 80), seed=10).to(torch.bfloat16).to(DEV)
     row_off = torch.tensor(_row_off(frames), dtype=torch.int32, device=DEV)
     outs = {}
-    for cap in (0, 256, 160):
+    for cap in (384, 256, 160, 0):                    # 384: whole utterances; 0: the library's own few-utterance rule
         with _lib.tuned(res2_max_t=cap):
             outs[cap] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(cfg[0])]
-    for cap in (256, 160):
+    for cap in (256, 160, 0):
         for i in range(cfg[0]):
-            assert torch.equal(outs[0][i], outs[cap][i]), (cap, i)
+            assert torch.equal(outs[384][i], outs[cap][i]), (cap, i)
