@@ -312,3 +312,24 @@ def test_full_size_batch256_properties(supernet):
     en = model(big, normalize=True)
     assert (en.norm(dim=1) - 1).abs().max() < 1e-5
     assert F.cosine_similarity(en, emb, dim=1).min() > 0.99999
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_sampled_subnets_match_oracle(precision, supernet, sup_state):
+    """24 subnets drawn by the reference's sampler (TDNNPath over DynamicTDNN.space(), dynamictdnn.py:792-879: depth
+    2-4, channels 128-512 in the space's steps, kernels 1/3/5, catconv 384-1536) on a small ragged batch, against the
+    CPU oracle: shapes no golden vector covers (the goldens hold 7 named subnets).  5 utterances < #CUs, so the Res2
+    chain runs under its few-utterance segment rule as well."""
+    sampler = sugar_amd.TDNNPath(supernet.space(verbose=False))
+    lens = [16000, 23456, 9999, 48000, 31000]
+    wavs = synth.ragged_waveforms(lens, seed=77)
+    worst_c, worst_r = 1.0, 0.0
+    for k in range(24):
+        cfg = sampler.sample()
+        model = _model(supernet, cfg, precision)
+        emb = model([w.to(DEV) for w in wavs])
+        want = ref_cpu.embed_ragged(ref_cpu.clone_state(sup_state, cfg), cfg[0], wavs)
+        c, r = _cos(emb, want).min().item(), _relerr(emb, want)
+        worst_c, worst_r = min(worst_c, c), max(worst_r, r)
+        assert c >= TOL[precision] and r < REL[precision], (k, cfg, c, r)
+    print("sampled subnets", precision, "worst cosine %.6f  worst rel L2 %.2e" % (worst_c, worst_r))
