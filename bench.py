@@ -33,6 +33,7 @@ WORKLOADS = {
     "base256": ("BASE", 256, 48000, "tdnn8m2g"),
     "largest256": ("LARGEST", 256, 48000, "tdnn8m2g"),
     "base64": ("BASE", 64, 48000, "tdnn8m2g"),       # diagnostic: every activation tensor fits the 256 MB Infinity Cache
+    "base1": ("BASE", 1, 48000, "tdnn8m2g"),         # diagnostic: one utterance, the latency floor of ~35 dependent kernels
     "wide256": ((3, [1024] * 4, [5] * 4, 1536), 256, 48000, "tdnn16m4g"),
 }
 SUPERNETS = {"tdnn8m2g": (80, 192, 4, 512, 5, 1536), "tdnn16m4g": (80, 192, 3, 1024, 5, 1536)}   # supernet_shapes arguments

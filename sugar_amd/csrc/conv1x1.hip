@@ -23,6 +23,8 @@
 // ~100 KB per CU in flight and let the hardware dispatcher balance the 1204 tiles.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace sugar {
@@ -611,7 +613,7 @@ constexpr int WR_TN = 64, WR_SUB = WR_TN * 128;   // a [64 frames x 64 k] sub-ti
 // frees 40 KiB of LDS for deeper stages (K = 512: SK 2 -> 4, layer1: SK 1 -> 7), a lone wave per SIMD
 // (pooling.linear1) stalls on it: 74.5 vs 69 us, so that instantiation keeps the staging.
 template <int KC, int CM, int SK, int NW = 16 / CM, bool STAGED = false>
-__global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args a, int n_ftiles, int n_slabs, int P) {
+__global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args a, int n_half, int n_slabs, int P) {
   static_assert(KC % SK == 0, "whole stages per tile");
   static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
   constexpr int DI = 8 / NW, SLAB = 16 * CM * NW;      // DMA instructions per wave and sub-tile; channels per workgroup
@@ -622,9 +624,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   // workgroups b and b + 8 (same XCD) take the two channel slabs of one frame range: the second read of x hits L2
   const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
   const int slab = j % n_slabs, p = xcd + 8 * (j / n_slabs);
-  const int t0 = (int)((int64_t)p * n_ftiles / P), t1 = (int)((int64_t)(p + 1) * n_ftiles / P);
-  if (t0 >= t1) return;
-  const int G = (t1 - t0) * KS;                       // stages of this workgroup
+  // The frames are dealt out in HALF tiles of 32: with whole 64-frame tiles 2 x 1 204 units on 256 workgroups (256 x 3 s)
+  // is 9.4 per workgroup and the launch lasts as long as the workgroups that got 10.  A range of an odd number of half
+  // tiles ends in a tile of which only the first 32 frames are its own: that tile skips the MFMAs of frames 32 .. 63
+  // (HALF below) and its epilogue stops at the range's last frame; the neighbour starts there with a tile of its own.
+  // (pooling.linear1, NW = 4: 256 ranges of 4.7 tiles gain nothing from halves and measured 1.5 % slower cold: whole tiles)
+  constexpr bool HALVES = NW == 8;
+  const int n_unit = HALVES ? n_half : (n_half + 1) >> 1, hs = HALVES ? 1 : 2;
+  const int h0 = hs * (int)((int64_t)p * n_unit / P), h1 = hs * (int)((int64_t)(p + 1) * n_unit / P);
+  if (h0 >= h1) return;
+  const int f0 = h0 * (WR_TN / 2), q_end = min(h1 * (WR_TN / 2), a.R);   // first frame of the range, one past its last
+  const int NTL = (h1 - h0 + 1) >> 1;                 // tiles of this workgroup, the last one HALF if the count is odd
+  const bool odd = (h1 - h0) & 1;
+  const int G = NTL * KS;                             // stages of this workgroup
   const int co_w = slab * SLAB + wv * (CM * 16);      // first channel of this wave
 
   // output-row map of the tiles in flight (a.orow): 4 slots of 64 int32 behind the ring, filled by wave 0 with one
@@ -637,9 +649,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   const int drow = wv * (8 * DI) + (lane >> 3);
   auto issue = [&](int g) {                           // stage g of this workgroup -> slot g % WR_NS
     if (WREG_KNOCK & 4) return;
-    const int slot = g % WR_NS, tile = t0 + g / KS, ks = g % KS;
+    const int slot = g % WR_NS, tf = f0 + (g / KS) * WR_TN, ks = g % KS;    // tf: first frame of the stage's tile
     if (a.orow && ks == 0 && wv == 0)                 // the counted waits below only get stricter by this extra request
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.orow + (size_t)tile * WR_TN + lane),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.orow + min(tf + lane, a.R - 1)),
                                        (__attribute__((address_space(3))) void*)(omap + ((g / KS) & 3) * WR_TN), 4, 0, 0);
 #pragma unroll
     for (int sub = 0; sub < SK; ++sub)
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
       for (int i = 0; i < DI; ++i) {
         const int row = drow + 8 * i;
         const int dchunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that belongs at LDS position lane & 7
-        const int xr = min(tile * WR_TN + row, a.R - 1);   // rows past R: any valid row, masked at the store
+        const int xr = min(tf + row, a.R - 1);             // rows past R: any valid row, masked at the store
         const bf16* src = a.x + (size_t)xr * a.ldx + dchunk * 8 + (ks * SK + sub) * TK;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)src,
@@ -705,11 +717,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
       else f[n] = *(const bf16x8*)(xb + swz(n * 16 + fr, 4 * h + fq));
     }
   };
-  auto mfmas = [&](int c, bf16x8 (&f)[4]) {
+  auto mfmas = [&](auto half_tag, int c, bf16x8 (&f)[4]) {
+    constexpr int NN = decltype(half_tag)::value ? 2 : 4;      // a HALF tile: frames 0 .. 31 only
 #pragma unroll
     for (int m = 0; m < CM; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < NN; ++n) {
         if (WREG_KNOCK & 1) asm volatile("" : "+v"(acc[m][n]) : "v"(wf[c][m]), "v"(f[n]));
         else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][m], f[n], acc[m][n], 0, 0, 0);
       }
@@ -719,8 +732,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   // 64 contiguous bytes per frame and wave (what the transposition through LDS used to build, without the LDS trip)
   static_assert(CM == 2, "the direct epilogue pairs two MFMA tiles per wave");
   unsigned char* ep = smem + WR_NS * WR_STAGE + wv * EPW;   // STAGED: this wave's [64 frames][32 channels] staging
-  auto epilogue = [&](int t) {
-    const int32_t* om = omap + ((t - t0) & 3) * WR_TN;
+  auto epilogue = [&](int lt) {                         // lt: tile of this workgroup, frames f0 + 64 lt ..
+    const int32_t* om = omap + (lt & 3) * WR_TN;
+    const int tf = f0 + lt * WR_TN;
     const int co = co_w + 8 * fq;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -745,10 +759,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
         *(bf16x8*)(ep + (n * 16 + fr) * EPI_STRIDE + 16 * fq) = o;
         continue;
       }
-      const int f = n * 16 + fr, q = t * WR_TN + f;
+      const int f = n * 16 + fr, q = tf + f;
       const int r = a.orow ? om[f] : q;                      // orow is -1 beyond the last padded row as well
       const u32x4 v = __builtin_bit_cast(u32x4, o);
-      if (q < a.R && r >= 0 && co < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
+      if (q < q_end && r >= 0 && co < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
         *(u32x4*)(a.y + (size_t)r * a.ldy + co) = v;
         if (a.y2 && co >= a.y2_from) *(u32x4*)(a.y2 + (size_t)r * a.ldy2 + co) = v;
       }
@@ -760,10 +774,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
 #pragma unroll
       for (int i = 0; i < WR_TN / RPP; ++i) {
         const int f = i * RPP + lane / LPR, ch = lane % LPR;
-        const int q = t * WR_TN + f, cs = co_w + ch * 8;
+        const int q = tf + f, cs = co_w + ch * 8;
         const int r = a.orow ? om[f] : q;
         const u32x4 v = *(const u32x4*)(ep + f * EPI_STRIDE + ch * 16);
-        if (q < a.R && r >= 0 && cs < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
+        if (q < q_end && r >= 0 && cs < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
           *(u32x4*)(a.y + (size_t)r * a.ldy + cs) = v;
           if (a.y2 && cs >= a.y2_from) *(u32x4*)(a.y2 + (size_t)r * a.ldy2 + cs) = v;
         }
@@ -779,14 +793,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   bf16x8 fb[2][4];
   frags(fb[0], 0, 0);
   int g = 0;
-  for (int t = t0; t < t1; ++t) {
+  auto tile_stages = [&](auto half_tag) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks, ++g) {
       const int cur = g % WR_NS;
 #pragma unroll
       for (int h = 0; h + 1 < H; ++h) {
         frags(fb[(h + 1) & 1], cur, h + 1);
-        mfmas(H * ks + h, fb[h & 1]);
+        mfmas(half_tag, H * ks + h, fb[h & 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
       // own rows of stage g + 1 have landed once at most the D - 1 younger stages are outstanding (epilogue stores in
@@ -799,10 +813,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (g + 1 + WR_D < G) issue(g + 1 + WR_D);       // into the slot stage g was read from
       if (g + 1 < G) frags(fb[0], (g + 1) % WR_NS, 0);
-      mfmas(H * ks + H - 1, fb[(H - 1) & 1]);
+      mfmas(half_tag, H * ks + H - 1, fb[(H - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    epilogue(t);
+  };
+  const int n_full = NTL - (odd ? 1 : 0);
+  for (int lt = 0; lt < n_full; ++lt) {
+    tile_stages(std::false_type{});
+    epilogue(lt);
+  }
+  if constexpr (HALVES) {
+    if (odd) {                                          // accumulators of frames 32 .. 63 stay zero; their rows are past q_end
+      tile_stages(std::true_type{});
+      epilogue(NTL - 1);
+    }
   }
 }
 
@@ -814,10 +838,10 @@ int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
   if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK, NW, STAGED>, smem, &opted)) return rc;
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu)) return rc;
-  const int n_slabs = (int)ceil_div(a.cout, 16 * CM * NW), n_ftiles = (int)ceil_div(a.R, WR_TN);
+  const int n_slabs = (int)ceil_div(a.cout, 16 * CM * NW), n_half = (int)ceil_div(a.R, WR_TN / 2);
   int P = n_cu / n_slabs / 8 * 8;
   if (P < 8) P = 8;
-  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK, NW, STAGED>), dim3(n_slabs * P), dim3(64 * NW), smem, s, a, n_ftiles, n_slabs, P);
+  hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK, NW, STAGED>), dim3(n_slabs * P), dim3(64 * NW), smem, s, a, n_half, n_slabs, P);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
