@@ -299,7 +299,7 @@ def main():
                        "streams": len(lanes), "preheat_steps": args.preheat,
                        "weights": "deterministic synthetic (sugar_amd/synth.py)"},
             "roofline": {"kernel": "%s catconv launch [%d frames x K %d -> %d]"
-                                   % ("gemm1x1_persist_kernel (256x256x64 LDS-DMA MFMA GEMM, ping-pong schedule, persistent split-tail grid)" if args.precision == "bf16"
+                                   % ("gemm1x1_persist_kernel (256x256x64 LDS-DMA MFMA GEMM, quadrant ping-pong schedule, persistent split-tail grid)" if args.precision == "bf16"
                                       else "conv_gemm_kernel<float,128,128>", R, depth * ch[0], ccat),
                          "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None,

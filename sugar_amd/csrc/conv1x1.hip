@@ -357,7 +357,15 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, in
 // vmcnt bookkeeping: vector memory operations of a wave return in issue order, and the prefetch is issued BEFORE the
 // epilogue's stores, so "my share of the prefetch has landed" is vmcnt(<stores issued since>): 16 for a full tile
 // without a duplicate store, otherwise the wave just waits for everything.
-template <int dummy = 0>
+// SCHED 1, the quadrant schedule (the shape of the 8-phase GEMM template of the CDNA programming guide): a k-tile is four
+// phases of 16 MFMAs, one 64 x 32 quadrant of the wave's 128 x 64 outputs each, on operand sub-tiles that stay in
+// registers (phase 1 reads b0 + a0, 2 reads b1, 3 reads a1, 4 reads nothing: a0 x b0, a0 x b1, a1 x b1, a1 x b0).  All
+// LDS reads of a k-tile are over after phase 3 (the B half after phase 2), so its stage can be re-filled from there on
+// and the DMA runs up to 1.5 k-tiles ahead with TWO instructions per wave and phase instead of eight in one burst:
+// activations of k-tile kt + 2 in phases 3 / 4, weights of kt + 1 in phases 1 / 2 (the weights are L2 hits, the shorter
+// lead is theirs).  Every phase is [reads + DMA | barrier | 16 MFMAs | barrier]; group 1 (wm = 1) runs one barrier
+// behind group 0, so one group's reads sit under the other's MFMAs.  Same sums in the same order: bit-identical.
+template <int SCHED = 0>
 __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const int xcd_first, const int stride, const int rounds) {
   constexpr int TM = 256, TN = 256, STAGE_BYTES = (TM + TN) * 128;
   constexpr int MI = TM / 32, NJ = TN / 64, CW = TM / 2, FW = TN / 4, WI = TM / 64, XI = TN / 64;
@@ -412,6 +420,23 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
                                        (__attribute__((address_space(3))) void*)(xbase + i * 1024), 16, 0, 0);
   };
+  auto dma_w = [&](int buf, int kt, int i0) {          // weight instructions i0, i0 + 1 of k-tile kt of the tile wtile points at
+    unsigned char* wbase = smem + buf * STAGE_BYTES + wv * (WI * 8) * 128;
+    const bf16* wk = wtile + kt * TK;
+#pragma unroll
+    for (int i = i0; i < i0 + 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
+                                       (__attribute__((address_space(3))) void*)(wbase + i * 1024), 16, 0, 0);
+  };
+  auto dma_x = [&](int buf, int kt, int i0, int n) {   // activation instructions i0 .. i0 + n - 1 (rows of xoff)
+    unsigned char* xbase = smem + buf * STAGE_BYTES + TM * 128 + wv * (XI * 8) * 128;
+    const bf16* xk = a.x + kt * TK;
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      if (i >= i0 && i < i0 + n)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
+                                         (__attribute__((address_space(3))) void*)(xbase + i * 1024), 16, 0, 0);
+  };
   auto tile_at = [&](int r, int& co_base, int& r_base) {
     const int vid = xcd_first + r * stride;
     co_base = (vid % a.n_co_tiles) * TM;
@@ -434,6 +459,95 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // k-tile 0 in stage 0; every wave out of its epilogue
     if (wm) asm volatile("s_barrier" ::: "memory");             // group 1 idles through phase 0
+    const int co_prev = co_base, r_prev = r_base;                // this round's tile
+    if constexpr (SCHED == 1) {
+      const bool more = r + 1 < rounds;
+      int co_next = co_base, r_next = r_base;
+      if (more) tile_at(r + 1, co_next, r_next);
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const unsigned char* wb = smem + cur * STAGE_BYTES;
+        const unsigned char* xb = wb + TM * 128;
+        bf16x8 a_[4][2], b0[2][2], b1[2][2];
+        auto read_a = [&](int m0) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a_[m][k] = *(const bf16x8*)(wb + swz(wm * CW + (m0 + m) * 16 + fr, 4 * k + fq));
+        };
+        auto read_b = [&](bf16x8 (&b)[2][2], int n0) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) b[n][k] = *(const bf16x8*)(xb + swz(wn * FW + (n0 + n) * 16 + fr, 4 * k + fq));
+        };
+        auto quad = [&](int m0, bf16x8 (&b)[2][2], int n0) {     // per accumulator: k = 0 then k = 1, as the half phases did
+          __builtin_amdgcn_s_setprio(1);                       // (keeps hipcc from moving MFMAs across the barriers; 0.8 %)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+              for (int n = 0; n < 2; ++n)
+                acc[m0 + m][n0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[m][k], b[n][k], acc[m0 + m][n0 + n], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        };
+        auto close_read = [&]() {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto close_mfma = [&](bool last) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (!last) asm volatile("s_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        // ---- phase 1: weights of the next k-tile (the next TILE's first one behind the last k-tile) ----------------
+        if (kt + 1 < nk) dma_w(cur ^ 1, kt + 1, 0);
+        else if (more) { wtile = a.w + (size_t)co_next * a.ldw; dma_w(0, 0, 0); }
+        if (kt == 0 && nk > 1) dma_x(1, 1, 0, XI);              // (its activations could not be staged under the epilogue)
+        read_b(b0, 0);
+        read_a(0);
+        close_read();
+        quad(0, b0, 0);
+        close_mfma(false);
+        // ---- phase 2 -------------------------------------------------------------------------------------------------
+        if (kt + 1 < nk) dma_w(cur ^ 1, kt + 1, 2);
+        else if (more) dma_w(0, 0, 2);
+        read_b(b1, 2);
+        close_read();
+        quad(0, b1, 2);
+        close_mfma(false);
+        // ---- phase 3: activations two k-tiles ahead, into the half of THIS stage that nobody reads any more -------------
+        const bool x_cur = kt + 2 < nk, x_next = kt + 2 == nk && more;
+        if (x_next) {                                           // the stream moves on to the next tile's rows
+#pragma unroll
+          for (int i = 0; i < XI; ++i) {
+            const int row = wv * (XI * 8) + i * 8 + srow;
+            const int xr = min(r_next + row, a.R - 1);
+            xoff[i] = (unsigned)xr * (unsigned)a.ldx + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 8);
+          }
+        }
+        if (x_cur) dma_x(cur, kt + 2, 0, 2);
+        else if (x_next) dma_x(cur, 0, 0, 2);
+        read_a(4);
+        close_read();
+        quad(4, b1, 2);
+        close_mfma(false);
+        // ---- phase 4 -------------------------------------------------------------------------------------------------
+        if (x_cur) dma_x(cur, kt + 2, 2, 2);
+        else if (x_next) dma_x(cur, 0, 2, 2);
+        // k-tile kt + 1 has landed (this wave's share) once only the activations issued in phases 3 / 4 are outstanding
+        if (kt + 1 < nk) {
+          if (x_cur || x_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        close_read();
+        quad(4, b0, 0);
+        close_mfma(wm && kt + 1 == nk);
+      }
+      co_base = co_next;
+      r_base = r_next;
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
       const unsigned char* wb = smem + (kt & 1) * STAGE_BYTES;
       const unsigned char* xb = wb + TM * 128;
@@ -458,9 +572,11 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    }
     // every wave is past the last LDS read of stage 0 (k-tile nk - 2; nk is even): the next tile's first k-tile goes there
-    const int co_cur = co_base, r_cur = r_base;
-    if (r + 1 < rounds) {
+    // (SCHED 1 has staged it during the last two k-tiles already and moved co_base / r_base on)
+    const int co_cur = SCHED == 1 ? co_prev : co_base, r_cur = SCHED == 1 ? r_prev : r_base;
+    if (SCHED == 0 && r + 1 < rounds) {
       tile_at(r + 1, co_base, r_base);
       point_at(co_base, r_base);
       stage(0, 0);
@@ -517,12 +633,13 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
 }
 
 // grid = the CU count (a multiple of 8); n_main = rounds * grid tiles of 256 x 256, then `tail` tiles cut into `split`
+template <int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm1x1_persist_kernel(Gemm1x1Args a, int n_main, int split, int tail) {
   const int bid = blockIdx.x, nwg = gridDim.x;
   const int xcd = bid & 7, seq = bid >> 3, wpx = nwg >> 3, rounds = n_main / nwg;
   // XCD x owns the contiguous tile range [x rounds wpx, (x + 1) rounds wpx); in round r its workgroups take consecutive
   // tiles of it, so co-tiles that share an activation row tile run at the same time on one XCD (shared L2)
-  gemm_tiles_persist<0>(a, xcd * rounds * wpx + seq, wpx, rounds);
+  gemm_tiles_persist<SCHED>(a, xcd * rounds * wpx + seq, wpx, rounds);
   if (bid >= tail * split) return;
   const int tile = n_main + bid / split, sub = bid - (bid / split) * split;
   const int co_base = (tile % a.n_co_tiles) * 256, r_tile = (tile / a.n_co_tiles) * 256;
@@ -557,9 +674,15 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
       !tune_get(TUNE_GEMM_NO_PERSIST)) {
     // two rounds or more: one persistent workgroup per CU (stage 1 + 8 x 8 704 bytes of epilogue staging behind it)
     constexpr int psmem = (256 + 256) * 128 + 8 * (16 * 2 * (128 * 2 + 16)) + 2 * 3072 * 4;   // + folded-BN vectors
-    static OptInMask popted{0};
-    if (int rc = lds_opt_in((const void*)gemm1x1_persist_kernel, psmem, &popted)) return rc;
-    hipLaunchKernelGGL(gemm1x1_persist_kernel, dim3(n_cu), dim3(512), psmem, s, a, n_main, split, tail);
+    if (a.K / TK >= 4 && !tune_get(TUNE_GEMM_NO_QUAD)) {       // quadrant schedule (SCHED 1)
+      static OptInMask qopted{0};
+      if (int rc = lds_opt_in((const void*)gemm1x1_persist_kernel<1>, psmem, &qopted)) return rc;
+      hipLaunchKernelGGL(gemm1x1_persist_kernel<1>, dim3(n_cu), dim3(512), psmem, s, a, n_main, split, tail);
+    } else {
+      static OptInMask popted{0};
+      if (int rc = lds_opt_in((const void*)gemm1x1_persist_kernel<0>, psmem, &popted)) return rc;
+      hipLaunchKernelGGL(gemm1x1_persist_kernel<0>, dim3(n_cu), dim3(512), psmem, s, a, n_main, split, tail);
+    }
     SUGAR_LAUNCH_CHECK();
     return SUGAR_OK;
   }

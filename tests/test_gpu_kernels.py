@@ -132,14 +132,18 @@ def test_pool1_weights_in_registers_is_bit_identical_to_tiles(frames):
 @pytest.mark.parametrize("cin,cout", [(1536, 1536), (1152, 1152)], ids=["1536", "1152"])
 @pytest.mark.parametrize("frames", [[301] * 40, [301] * 100, [301] * 110 + [70]], ids=["1round", "2rounds+tail", "3rounds+split4"])
 def test_wide_gemm_schedules_are_bit_identical(frames, cin, cout):
-    """catconv shape with full 256 x 256 rounds.  What the forward runs -- ping-pong schedule, split tail, and from two
-    rounds up ONE persistent workgroup per CU that prefetches its next tile's first k-tile under the epilogue -- against
-    one workgroup per tile, the in-step schedule and the uniform grid: the same bytes, and F.conv1d within bf16.
+    """catconv shape with full 256 x 256 rounds.  What the forward runs -- split tail, and from two rounds up ONE
+    persistent workgroup per CU on the quadrant schedule whose DMA stream runs across tile boundaries -- against the
+    persistent two-half ping-pong, one workgroup per tile, the in-step schedule and the uniform grid: the same bytes,
+    and F.conv1d within bf16.
     1152 channels: 4.5 channel tiles (the last one half empty: masked stores, uncounted vmcnt wait) and 18 k-tiles."""
     case = (cin, cout, 1, 1, 1, frames)
     pp, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
     with _lib.tuned(gemm_no_persist=1):
         per_tile, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
+    with _lib.tuned(gemm_no_quad=1):                 # persistent loop on the two-half ping-pong instead of the quadrant schedule
+        halves, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
+    assert torch.equal(pp, halves)
     with _lib.tuned(gemm_no_pingpong=1):
         instep, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
     with _lib.tuned(gemm_uniform=1):
