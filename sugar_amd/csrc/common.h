@@ -72,7 +72,7 @@ enum {
   TUNE_RES2_MAX_T,            // frames one Res2 workgroup holds (0 = the kernel's 384)
   TUNE_GENERIC_LAYER1,        // != 0: layer1 through the generic masked-load conv
   TUNE_GEMM_NO_PERSIST,       // != 0: the wide GEMM as one workgroup per tile (no persistent loop)
-  TUNE_GEMM_NO_QUAD,          // != 0: the persistent wide GEMM on the two-half ping-pong schedule instead of the quadrant one
+  TUNE_GEMM_NO_QUAD,          // persistent wide GEMM: 0 quadrant schedule in two phases per k-tile, 2 in four phases, 1 two-half ping-pong
   TUNE_COUNT
 };
 int64_t tune_get(int key);

@@ -357,8 +357,8 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, in
 // vmcnt bookkeeping: vector memory operations of a wave return in issue order, and the prefetch is issued BEFORE the
 // epilogue's stores, so "my share of the prefetch has landed" is vmcnt(<stores issued since>): 16 for a full tile
 // without a duplicate store, otherwise the wave just waits for everything.
-// SCHED 1, the quadrant schedule (the shape of the 8-phase GEMM template of the CDNA programming guide): a k-tile is four
-// phases of 16 MFMAs, one 64 x 32 quadrant of the wave's 128 x 64 outputs each, on operand sub-tiles that stay in
+// SCHED 1 / 2, the quadrant schedule (the shape of the 8-phase GEMM template of the CDNA programming guide): a k-tile is four
+// phases of 16 MFMAs (SCHED 1; SCHED 2, the default, runs them as two phases of 32: half the barriers, 0.314 -> 0.298 ms), one 64 x 32 quadrant of the wave's 128 x 64 outputs each, on operand sub-tiles that stay in
 // registers (phase 1 reads b0 + a0, 2 reads b1, 3 reads a1, 4 reads nothing: a0 x b0, a0 x b1, a1 x b1, a1 x b0).  All
 // LDS reads of a k-tile are over after phase 3 (the B half after phase 2), so its stage can be re-filled from there on
 // and the DMA runs up to 1.5 k-tiles ahead with TWO instructions per wave and phase instead of eight in one burst:
@@ -460,7 +460,8 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // k-tile 0 in stage 0; every wave out of its epilogue
     if (wm) asm volatile("s_barrier" ::: "memory");             // group 1 idles through phase 0
     const int co_prev = co_base, r_prev = r_base;                // this round's tile
-    if constexpr (SCHED == 1) {
+    if constexpr (SCHED >= 1) {
+      constexpr bool TWO = SCHED == 2;      // two phases of 32 MFMAs per k-tile instead of four of 16 (half the barriers)
       const bool more = r + 1 < rounds;
       int co_next = co_base, r_next = r_base;
       if (more) tile_at(r + 1, co_next, r_next);
@@ -507,14 +508,17 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
         if (kt == 0 && nk > 1) dma_x(1, 1, 0, XI);              // (its activations could not be staged under the epilogue)
         read_b(b0, 0);
         read_a(0);
-        close_read();
-        quad(0, b0, 0);
-        close_mfma(false);
+        if (!TWO) {
+          close_read();
+          quad(0, b0, 0);
+          close_mfma(false);
+        }
         // ---- phase 2 -------------------------------------------------------------------------------------------------
         if (kt + 1 < nk) dma_w(cur ^ 1, kt + 1, 2);
         else if (more) dma_w(0, 0, 2);
         read_b(b1, 2);
         close_read();
+        if (TWO) quad(0, b0, 0);
         quad(0, b1, 2);
         close_mfma(false);
         // ---- phase 3: activations two k-tiles ahead, into the half of THIS stage that nobody reads any more -------------
@@ -530,9 +534,11 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
         if (x_cur) dma_x(cur, kt + 2, 0, 2);
         else if (x_next) dma_x(cur, 0, 0, 2);
         read_a(4);
-        close_read();
-        quad(4, b1, 2);
-        close_mfma(false);
+        if (!TWO) {
+          close_read();
+          quad(4, b1, 2);
+          close_mfma(false);
+        }
         // ---- phase 4 -------------------------------------------------------------------------------------------------
         if (x_cur) dma_x(cur, kt + 2, 2, 2);
         else if (x_next) dma_x(cur, 0, 2, 2);
@@ -542,6 +548,7 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         close_read();
+        if (TWO) quad(4, b1, 2);
         quad(4, b0, 0);
         close_mfma(wm && kt + 1 == nk);
       }
@@ -575,7 +582,7 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
     }
     // every wave is past the last LDS read of stage 0 (k-tile nk - 2; nk is even): the next tile's first k-tile goes there
     // (SCHED 1 has staged it during the last two k-tiles already and moved co_base / r_base on)
-    const int co_cur = SCHED == 1 ? co_prev : co_base, r_cur = SCHED == 1 ? r_prev : r_base;
+    const int co_cur = SCHED >= 1 ? co_prev : co_base, r_cur = SCHED >= 1 ? r_prev : r_base;
     if (SCHED == 0 && r + 1 < rounds) {
       tile_at(r + 1, co_base, r_base);
       point_at(co_base, r_base);
@@ -674,11 +681,16 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
       !tune_get(TUNE_GEMM_NO_PERSIST)) {
     // two rounds or more: one persistent workgroup per CU (stage 1 + 8 x 8 704 bytes of epilogue staging behind it)
     constexpr int psmem = (256 + 256) * 128 + 8 * (16 * 2 * (128 * 2 + 16)) + 2 * 3072 * 4;   // + folded-BN vectors
-    if (a.K / TK >= 4 && !tune_get(TUNE_GEMM_NO_QUAD)) {       // quadrant schedule (SCHED 1)
+    const int64_t sched = a.K / TK >= 4 ? tune_get(TUNE_GEMM_NO_QUAD) : 1;
+    if (sched == 0) {                                           // quadrant schedule, two 32-MFMA phases per k-tile
+      static OptInMask q2opted{0};
+      if (int rc = lds_opt_in((const void*)gemm1x1_persist_kernel<2>, psmem, &q2opted)) return rc;
+      hipLaunchKernelGGL(gemm1x1_persist_kernel<2>, dim3(n_cu), dim3(512), psmem, s, a, n_main, split, tail);
+    } else if (sched == 2) {                                    // quadrant schedule, four 16-MFMA phases
       static OptInMask qopted{0};
       if (int rc = lds_opt_in((const void*)gemm1x1_persist_kernel<1>, psmem, &qopted)) return rc;
       hipLaunchKernelGGL(gemm1x1_persist_kernel<1>, dim3(n_cu), dim3(512), psmem, s, a, n_main, split, tail);
-    } else {
+    } else {                                                    // two-half ping-pong
       static OptInMask popted{0};
       if (int rc = lds_opt_in((const void*)gemm1x1_persist_kernel<0>, psmem, &popted)) return rc;
       hipLaunchKernelGGL(gemm1x1_persist_kernel<0>, dim3(n_cu), dim3(512), psmem, s, a, n_main, split, tail);

@@ -141,9 +141,10 @@ def test_wide_gemm_schedules_are_bit_identical(frames, cin, cout):
     pp, want = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
     with _lib.tuned(gemm_no_persist=1):
         per_tile, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
-    with _lib.tuned(gemm_no_quad=1):                 # persistent loop on the two-half ping-pong instead of the quadrant schedule
-        halves, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
-    assert torch.equal(pp, halves)
+    for sched in (1, 2):                             # persistent loop on the two-half ping-pong / the four-phase quadrant schedule
+        with _lib.tuned(gemm_no_quad=sched):
+            other, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
+        assert torch.equal(pp, other), sched
     with _lib.tuned(gemm_no_pingpong=1):
         instep, _ = _conv_case(_lib.SUGAR_BF16, *case, with_x2=False, seed=6)
     with _lib.tuned(gemm_uniform=1):
