@@ -725,6 +725,9 @@ int launch_split(const Gemm1x1Args& a, hipStream_t s) {
 #ifndef WREG_KNOCK
 #define WREG_KNOCK 0
 #endif
+#ifndef WREG_SPREAD
+#define WREG_SPREAD 1
+#endif
 constexpr int WR_TN = 64, WR_SUB = WR_TN * 128;   // a [64 frames x 64 k] sub-tile: 8 KiB
 
 // Round 2, measured and dropped (tools/wreg_bench, R = 77 056, all bit-identical; profiles/r02_wreg_variants.log): the
@@ -782,16 +785,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
 
   // ---- activation DMA: wave wv fills rows 8 DI wv .. + 8 DI - 1 of a stage ----------------------------------------
   const int drow = wv * (8 * DI) + (lane >> 3);
-  auto issue = [&](int g) {                           // stage g of this workgroup -> slot g % WR_NS
+  // sub-tiles s0 .. s1 - 1 of stage g of this workgroup -> slot g % WR_NS
+  auto issue_part = [&](int g, int s0, int s1) {
     if (WREG_KNOCK & 4) return;
     const int slot = g % WR_NS, tf = f0 + (g / KS) * WR_TN, ks = g % KS;    // tf: first frame of the stage's tile
-    if (a.orow && ks == 0 && wv == 0)                 // the counted waits below only get stricter by this extra request
+    if (s0 == 0 && a.orow && ks == 0 && wv == 0)      // the counted waits below only get stricter by this extra request
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.orow + min(tf + lane, a.R - 1)),
                                        (__attribute__((address_space(3))) void*)(omap + ((g / KS) & 3) * WR_TN), 4, 0, 0);
 #pragma unroll
     for (int sub = 0; sub < SK; ++sub)
 #pragma unroll
       for (int i = 0; i < DI; ++i) {
+        if (sub < s0 || sub >= s1) continue;
         const int row = drow + 8 * i;
         const int dchunk = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that belongs at LDS position lane & 7
         const int xr = min(tf + row, a.R - 1);             // rows past R: any valid row, masked at the store
@@ -801,6 +806,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
             (__attribute__((address_space(3))) void*)(smem + slot * WR_STAGE + sub * WR_SUB + (wv * DI + i) * 1024), 16, 0, 0);
       }
   };
+  auto issue = [&](int g) { issue_part(g, 0, SK); };
 #pragma unroll
   for (int g = 0; g < WR_D; ++g)
     if (g < G) issue(g);                           // the ring fills while the weights load
@@ -924,7 +930,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // once: weights and the first D stages
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (WR_D < G) issue(WR_D);
+  // The DMA of a stage goes out one sub-tile at a time: the first right behind the barrier that frees its slot, the
+  // others in front of every second half of the stage that follows (WREG_SPREAD; all eight waves issuing the whole
+  // stage at once held every wave ~60 clocks per instruction before its next MFMAs)
+  if (WR_D < G) issue_part(WR_D, 0, WREG_SPREAD ? 1 : SK);
   bf16x8 fb[2][4];
   frags(fb[0], 0, 0);
   int g = 0;
@@ -934,6 +943,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
       const int cur = g % WR_NS;
 #pragma unroll
       for (int h = 0; h + 1 < H; ++h) {
+        if (WREG_SPREAD && (h & 1) && (h + 1) / 2 < SK && g + WR_D < G) issue_part(g + WR_D, (h + 1) / 2, (h + 1) / 2 + 1);
         frags(fb[(h + 1) & 1], cur, h + 1);
         mfmas(half_tag, H * ks + h, fb[h & 1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -946,7 +956,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
       }
       if (WREG_KNOCK & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (g + 1 + WR_D < G) issue(g + 1 + WR_D);       // into the slot stage g was read from
+      if (g + 1 + WR_D < G) issue_part(g + 1 + WR_D, 0, WREG_SPREAD ? 1 : SK);   // into the slot stage g was read from
       if (g + 1 < G) frags(fb[0], (g + 1) % WR_NS, 0);
       mfmas(half_tag, H * ks + H - 1, fb[(H - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
