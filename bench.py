@@ -33,6 +33,7 @@ WORKLOADS = {
     "base256": ("BASE", 256, 48000, "tdnn8m2g"),
     "largest256": ("LARGEST", 256, 48000, "tdnn8m2g"),
     "base64": ("BASE", 64, 48000, "tdnn8m2g"),       # diagnostic: every activation tensor fits the 256 MB Infinity Cache
+    "base128": ("BASE", 128, 48000, "tdnn8m2g"),     # diagnostic: 3.5 rounds of catconv tiles
     "base1": ("BASE", 1, 48000, "tdnn8m2g"),         # diagnostic: one utterance, the latency floor of ~35 dependent kernels
     "wide256": ((3, [1024] * 4, [5] * 4, 1536), 256, 48000, "tdnn16m4g"),
 }
