@@ -65,7 +65,7 @@ int device_cu_count(int* n_cu);
 // Tunables (subnet.hip): read ONCE from the environment (SUGAR_<NAME>), afterwards only through sugar_tune_set /
 // sugar_tune_get (atomics: safe against concurrent launches).  They exist for parity tests and in-job A/B runs.
 enum {
-  TUNE_GEMM_WREG_MIN_R = 0,   // K = 512 convs use the weights-in-registers GEMM from this many frames up (43008)
+  TUNE_GEMM_WREG_MIN_R = 0,   // K = 512 convs use the weights-in-registers GEMM from this many frames up (19200; pooling.linear1 from 1.5 x that)
   TUNE_GEMM_UNIFORM,          // != 0: wide 1x1 convs on the uniform 256 x 256 grid (no split tail)
   TUNE_GEMM_NO_PINGPONG,      // != 0: both waves of a SIMD in step in the wide GEMM
   TUNE_GENERIC_RES2,          // != 0: Res2 chain as 7 generic launches

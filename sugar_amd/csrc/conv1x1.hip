@@ -1116,7 +1116,9 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // K = 512, large R: weights-in-registers kernel (a quarter of the DMA bytes per MFMA, x read once from HBM).
       // Same job, Base 256 x 3 s (R = 77 056): one stream 178.4 k vs 177.0 k emb/s, two streams 199.8 k vs 191.0 k.
       // Its weight load is a fixed ~7 us per launch, so short inputs stay on the tile kernel (R = 12 040: 22 vs 15 us);
-      // whole forwards cross over at ~140 x 3 s (profiles/r01_wreg_threshold.log: B = 128 equal, 160 + 1 %, 384 + 6 %).
+      // whole forwards crossed over at ~140 x 3 s in round 1 (profiles/r01_wreg_threshold.log); with the round-2 kernel
+      // (pre-packed fragments, half-tile ranges, spread DMA issue) at ~64 x 3 s: 128 x 3 s 175.5 k -> 185.4 k emb/s,
+      // 64 x 3 s equal (profiles/r02_wreg_threshold.log), so the default threshold is 19 200 frames.
       // The tunable gemm_wreg_min_r moves the threshold (0: always, for the parity tests; huge: never, for A/B runs).
       const int64_t wreg_min_r = tune_get(TUNE_GEMM_WREG_MIN_R);
       // (K = 256 .. 448 instantiations were measured on the NAS sweep, tools/sweep_bench.py: 31.5-32.7 vs 30.1-31.0 ms
@@ -1139,7 +1141,9 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
   }
   // pooling.linear1 at full width (K = 1536 -> 128 + tanh) on large inputs: weights in registers, only the activations
   // stream (the tunable gemm_wreg_min_r switches it together with the 512-channel convs)
-  if (L.wfrag && a.K == 1536 && L.cout == 128 && R >= tune_get(TUNE_GEMM_WREG_MIN_R)) {
+  // (its crossover lies higher than the convs': one wave per SIMD; 64 x 3 s 0.0202 vs 0.0252 ms on the tile kernel,
+  // 128 x 3 s 0.0423 vs 0.0401)
+  if (L.wfrag && a.K == 1536 && L.cout == 128 && R >= tune_get(TUNE_GEMM_WREG_MIN_R) / 2 * 3) {
     a.wfrag = (const bf16*)L.wfrag;
     // (walking the frame tiles from the last one down, so that the first reads hit what the catconv launch wrote last
     // into the Infinity Cache, measured no difference: 70.8 vs 70.9 us in the pipeline)

@@ -108,7 +108,7 @@ def test_conv_bf16(case):
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] == 512 and c[1] == 512 and c[2] == 1],
                          ids=lambda c: "frames%dx%d_f%d" % (len(c[5]), c[5][0], c[4]))
 def test_conv512_weights_in_registers_is_bit_identical_to_tiles(case):
-    """The K = 512 convs switch to gemm_wreg_kernel at R >= 43008; both kernels must give the same bits at any R."""
+    """The K = 512 convs switch to gemm_wreg_kernel at R >= 19200; both kernels must give the same bits at any R."""
     with _lib.tuned(gemm_wreg_min_r=0):
         wreg, want = _conv_case(_lib.SUGAR_BF16, *case[:6], with_x2=False, seed=5)
     with _lib.tuned(gemm_wreg_min_r=1 << 40):
