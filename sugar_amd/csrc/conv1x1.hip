@@ -357,9 +357,12 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_split_kernel(Gemm1x1Args a, in
 // vmcnt bookkeeping: vector memory operations of a wave return in issue order, and the prefetch is issued BEFORE the
 // epilogue's stores, so "my share of the prefetch has landed" is vmcnt(<stores issued since>): 16 for a full tile
 // without a duplicate store, otherwise the wave just waits for everything.
-// SCHED 1 / 2, the quadrant schedule (the shape of the 8-phase GEMM template of the CDNA programming guide): a k-tile is four
-// phases of 16 MFMAs (SCHED 1; SCHED 2, the default, runs them as two phases of 32: half the barriers, 0.314 -> 0.298 ms), one 64 x 32 quadrant of the wave's 128 x 64 outputs each, on operand sub-tiles that stay in
-// registers (phase 1 reads b0 + a0, 2 reads b1, 3 reads a1, 4 reads nothing: a0 x b0, a0 x b1, a1 x b1, a1 x b0).  All
+// SCHED 0 is the two-half ping-pong of gemm_tile (kept for A/B runs and the bit-identity tests).
+// SCHED 1 / 2, the quadrant schedule (the shape of the 8-phase GEMM template of the CDNA programming guide): a k-tile is
+// four phases of 16 MFMAs, one 64 x 32 quadrant of the wave's 128 x 64 outputs each, on operand sub-tiles that stay in
+// registers (phase 1 reads b0 + a0, 2 reads b1, 3 reads a1, 4 reads nothing: a0 x b0, a0 x b1, a1 x b1, a1 x b0).
+// SCHED 2, the default, leaves out the barriers between phases 1 / 2 and 3 / 4: two phases of 32 MFMAs, half the
+// barriers (catconv 0.314 -> 0.298 ms).  All
 // LDS reads of a k-tile are over after phase 3 (the B half after phase 2), so its stage can be re-filled from there on
 // and the DMA runs up to 1.5 k-tiles ahead with TWO instructions per wave and phase instead of eight in one burst:
 // activations of k-tile kt + 2 in phases 3 / 4, weights of kt + 1 in phases 1 / 2 (the weights are L2 hits, the shorter
