@@ -60,6 +60,9 @@ struct Chunk<bf16> {
 // order.  (Round 1 ran the whole MLP as one workgroup per utterance: 512 KiB of weights per workgroup at the ~50 GB/s
 // a single CU pulls from L2 with dependent loads = 14.6 us per launch, as long as the mean pass itself.)
 constexpr int SE_SEG = 2048;
+#ifndef SE_WPRE
+#define SE_WPRE 1
+#endif
 
 __device__ __forceinline__ int se_slot(const int32_t* row_off, int b) { return row_off[b] / SE_SEG + b; }
 
@@ -77,6 +80,18 @@ __global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, i
   const int s = s_utt + seg0, n = min(SE_SEG, n_utt - seg0);
   const int tx = tid & 7, ty = tid >> 3;
   const int c0 = (blockIdx.x * 8 + tx) * E;
+  // The reduce-layer weights of this slab (32 per thread) do not depend on y: with hid <= 128 and a full slab they are
+  // requested first, so that their L2 round trip runs under the pass over y instead of behind it (every workgroup of
+  // the launch reaches that point at the same time: 64 MB of L2 reads in one burst)
+  const int hid = se.hid, cbase = blockIdx.x * SC;
+  const int wj = min(tid & 127, hid - 1), whalf = tid >> 7;
+  const bool wpre = SE_WPRE && hid <= 128 && cbase + SC <= c_p;
+  float wq[SC / 2];
+  if (wpre) {
+    const float* __restrict__ wrow = se.w1t + (size_t)(cbase + whalf * (SC / 2)) * hid + wj;
+#pragma unroll
+    for (int k = 0; k < SC / 2; ++k) wq[k] = wrow[(size_t)k * hid];
+  }
   float acc[E];
 #pragma unroll
   for (int i = 0; i < E; ++i) acc[i] = 0.f;
@@ -101,8 +116,17 @@ __global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, i
   }
   __syncthreads();
   // this slab's share of reduce.weight x mean: thread (j, half) walks SC / 2 channels; weight rows of padded channels are 0
-  const int hid = se.hid, cbase = blockIdx.x * SC;
   float* out = hpart + ((size_t)(se_slot(row_off, b) + blockIdx.z) * nslab + blockIdx.x) * hid;
+  if (wpre) {                                          // same sums in the same order as the loop below
+    const int j = tid & 127, cc0 = whalf * (SC / 2);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < SC / 2; ++k) t = fmaf(wq[k], msum[cc0 + k], t);
+    hp2[whalf][j] = j < hid ? t : 0.f;
+    __syncthreads();
+    if (tid < 128 && j < hid) out[j] = hp2[0][tid] + hp2[1][tid];
+    return;
+  }
   for (int j0 = 0; j0 < hid; j0 += 128) {
     const int j = j0 + (tid & 127), half = tid >> 7;
     float t = 0.f;
