@@ -73,6 +73,7 @@ enum {
   TUNE_GENERIC_LAYER1,        // != 0: layer1 through the generic masked-load conv
   TUNE_GEMM_NO_PERSIST,       // != 0: the wide GEMM as one workgroup per tile (no persistent loop)
   TUNE_GEMM_NO_QUAD,          // persistent wide GEMM: 0 quadrant schedule in two phases per k-tile, 2 in four phases, 1 two-half ping-pong
+  TUNE_RES2_NO_DB,            // != 0: Res2 chain kernel without the double-buffered u tile (two barriers per step)
   TUNE_COUNT
 };
 int64_t tune_get(int key);
@@ -155,6 +156,13 @@ static inline uint16_t host_f32_to_bf16(float f) {
 int launch_build_rowseg(const int32_t* d_row_off, int B, int t_max, int2* d_rowseg, hipStream_t s);
 
 // ---- implicit-GEMM conv (conv_gemm.hip) ---------------------------------------------------------
+// ReLU in ONE instruction: fmaxf(v, 0) compiles to a canonicalising v_max_f32 v, v, v in front of the max (the compiler
+// cannot know that an MFMA result is no signalling NaN), i.e. two VALU instructions per accumulator in every epilogue
+__device__ __forceinline__ float relu_f32(float v) {
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
 enum { EPI_RELU = 1, EPI_AFFINE = 2, EPI_TANH = 4 };
 
 struct ConvLayer {       // packed, device-resident

@@ -287,7 +287,7 @@ __device__ __forceinline__ void gemm_tile(const Gemm1x1Args& a, const int co_bas
         f32x4 v = acc[m][pass * HN + nn];
         if (relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = relu_f32(v[e]);
         }
         v = v * sc + sh;
         if (tanh_) {
@@ -610,7 +610,7 @@ __device__ __forceinline__ void gemm_tiles_persist(const Gemm1x1Args& a, const i
           acc[m][pass * HN + nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = relu_f32(v[e]);
           }
           v = v * sc + sh;
           if (tanh_) {
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
         acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = relu_f32(v[e]);
         }
         v = v * scp[m] + shp[m];
         if (tanh_) {

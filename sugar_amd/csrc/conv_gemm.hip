@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
         f32x4 v = {acc[m][n][4 * q + 0], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
         if (relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = relu_f32(v[e]);
         }
         if (affine) {
           const f32x4 sc = *(const f32x4*)(a.scale + co), sh = *(const f32x4*)(a.shift + co);

@@ -78,7 +78,10 @@ __device__ __forceinline__ u32x4 add_bf16x8(u32x4 xa, u32x4 xb) {
 // bit-identical outputs but 0.186 ms per step against 0.131 (more fragment reads of the shared weight panel per MFMA,
 // 12-wave barriers), and cutting 301-frame utterances into two time segments for two workgroups per CU 0.205 ms.
 // WREG = 16-byte weight chunks each thread stages per step: 3 (k_pad <= 192) or 5 (k_pad <= 320)
-template <int MT, int R2_TPW, int WREG>
+// DB (the default where it fits 160 KiB: 64-channel groups of 3 taps): u and the weight panel are double-buffered and a
+// wave's own rows of the NEXT u buffer serve as its sp staging area, so the epilogue of step j leaves u_{j+1} in place
+// and a step needs ONE workgroup barrier (without DB: staging tiles of their own, u_{j+1} written between two barriers).
+template <int MT, int R2_TPW, int WREG, bool DB>
 __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NI = (MT + 1) / 2;                      // 16-byte chunk items per lane and frame tile
@@ -110,15 +113,16 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   const int u_bytes = (u_rows * urow + 255) & ~255;
   const int wstride = a.k_pad * 2;                      // weight rows: groups of 8 chunks, chunk ^= row & 7 inside a group
   const int wchunks = a.k_pad >> 3;                     // chunks per weight row (multiple of 8)
-  unsigned char* u = smem;
-  unsigned char* wl = smem + u_bytes;
+  constexpr int NB = DB ? 2 : 1;
+  unsigned char* u = smem;                              // the u tile of the current step (DB: alternates)
+  unsigned char* wl = smem + NB * u_bytes;              // its weight panel
   constexpr int OT = R2_TPW <= 3 ? R2_TPW : 1;          // sp staging tiles per wave
-  unsigned char* ob = wl + 64 * wstride + wv * (OT * 16 * urow);        // this wave's sp staging tiles [16][wp]
-  float* ss = (float*)(wl + 64 * wstride + R2_WAVES * OT * 16 * urow);  // [7][scale 64 | shift 64]
+  unsigned char* ob = wl + 64 * wstride + wv * (OT * 16 * urow);        // (!DB) this wave's sp staging tiles [16][wp]
+  float* ss = (float*)(wl + NB * 64 * wstride + (DB ? 0 : R2_WAVES * OT * 16 * urow));  // [7][scale 64 | shift 64]
   const int nks = a.k_pad >> 5;                         // k-steps of 32
 
   // zero the whole u tile once: halo rows and frames >= T stay zero for the whole chain
-  for (int i = tid; i < u_bytes / 16; i += 512) ((u32x4*)u)[i] = (u32x4){0u, 0u, 0u, 0u};
+  for (int i = tid; i < NB * u_bytes / 16; i += 512) ((u32x4*)u)[i] = (u32x4){0u, 0u, 0u, 0u};
   for (int i = tid; i < R2_STEPS * 128; i += 512) {
     const int j = i >> 7, c = i & 63;
     ss[i] = (i & 64) ? a.shift[j][c] : a.scale[j][c];
@@ -142,10 +146,10 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
 #pragma unroll
     for (int i = 0; i < WREG; ++i) wreg[i] = *(const u32x4*)(a.w[j] + max(wsrc[i], 0));   // unconditional, see load_x
   };
-  auto store_w = [&]() {
+  auto store_w = [&](unsigned char* wdst_base) {
 #pragma unroll
     for (int i = 0; i < WREG; ++i)
-      if (wsrc[i] >= 0) *(u32x4*)(wl + wdst[i]) = wreg[i];
+      if (wsrc[i] >= 0) *(u32x4*)(wdst_base + wdst[i]) = wreg[i];
   };
 
   // row-contiguous chunk items of a 16-frame tile: item = lane + 64 i -> (frame it / nch, chunk it % nch)
@@ -165,6 +169,31 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   // stamps showed a one-step prefetch still exposed ~2 us of memory latency per step, with every CU bursting at once.
   constexpr bool DEEP = R2_TPW <= 3;
   u32x4 xs[2][R2_TPW][NI];
+  // Byte offsets that do not change from step to step, computed once and pinned in registers (recomputed in all 7
+  // unrolled epilogues they were a third of the epilogue's VALU time: 24 quarter-rate 32-bit multiplies per step):
+  //   uoff: item (n, i) inside a u buffer;  yoff / xoff: its row and chunk in y / x (without the group's column);
+  //   soff / smx: the MFMA-layout rows and chunk slots stage_sp writes (DB: in the next u buffer)
+  int uoff[R2_TPW][NI], yoff[R2_TPW][NI], xoff[R2_TPW][NI], soff[R2_TPW], smx[MT];
+#pragma unroll
+  for (int n = 0; n < R2_TPW; ++n) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (wv + R2_WAVES * n) * 16 + irow[i];
+      const int row = min(r, 16 * NT - 1) + halo;       // (irow 16 = no such item: any row of the buffer, never used)
+      uoff[n][i] = row * urow + ((ich[i] ^ (row & swz_mask)) << 4);
+      yoff[n][i] = (r * a.ld + ich[i] * 8) * 2;
+      xoff[n][i] = (min((wv + R2_WAVES * n) * 16 + min(irow[i], 15), T - 1) * a.ld + ich[i] * 8) * 2;   // a valid row for every lane
+      asm volatile("" : "+v"(uoff[n][i]), "+v"(yoff[n][i]), "+v"(xoff[n][i]));
+    }
+    soff[n] = ((wv + R2_WAVES * n) * 16 + f + halo) * urow;
+    asm volatile("" : "+v"(soff[n]));
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co = m * 16 + 4 * q, srow = f + halo;     // (16-row tiles: row & swz_mask does not depend on the tile)
+    smx[m] = (((co >> 3) ^ (srow & swz_mask)) << 4) + (co & 7) * 2;
+    asm volatile("" : "+v"(smx[m]));
+  }
   auto item_ok = [&](int n, int i) { return n < ntw && irow[i] < 16 && (wv + R2_WAVES * n) * 16 + irow[i] < T; };
   auto load_x = [&](int j, int buf) {
 #pragma unroll
@@ -173,9 +202,9 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
       for (int i = 0; i < NI; ++i) {
         // unconditional load from a clamped (always valid) address, then select: a branch around each load would
         // make hipcc wait vmcnt(0) per element and serialise the memory round trips
-        const int r = min((wv + R2_WAVES * n) * 16 + min(irow[i], 15), T - 1);
-        if (R2_NT) xs[buf][n][i] = __builtin_nontemporal_load((const u32x4*)(xb + r * a.ld + j * wp + ich[i] * 8));
-        else xs[buf][n][i] = *(const u32x4*)(xb + r * a.ld + j * wp + ich[i] * 8);   // items not item_ok are never used
+        const unsigned char* src = (const unsigned char*)(xb + j * wp) + xoff[n][i];   // items not item_ok are never used
+        if (R2_NT) xs[buf][n][i] = __builtin_nontemporal_load((const u32x4*)src);
+        else xs[buf][n][i] = *(const u32x4*)src;
       }
   };
   auto write_u = [&](int buf) {
@@ -183,10 +212,7 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
     for (int n = 0; n < R2_TPW; ++n)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
-        if (item_ok(n, i)) {
-          const int row = (wv + R2_WAVES * n) * 16 + irow[i] + halo;
-          *(u32x4*)(u + row * urow + ((ich[i] ^ (row & swz_mask)) << 4)) = xs[buf][n][i];
-        }
+        if (item_ok(n, i)) *(u32x4*)(u + uoff[n][i]) = xs[buf][n][i];
   };
 
   const int inv_wp = (65536 + wp - 1) / wp;
@@ -196,11 +222,20 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   __syncthreads();                                      // zero fill complete before the first u write
   R2_STAMP();
   write_u(0);
-  store_w();
+  store_w(wl);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  unsigned char* const u_first = u;
+  unsigned char* const wl_first = wl;
 #pragma unroll
   for (int j = 0; j < R2_STEPS; ++j) {                  // fully unrolled: the xs buffer index is static
     const bool last = j + 1 == R2_STEPS;
+    // DB: this step reads buffer j & 1 and builds u_{j+1} / stages the next panel in the other one
+    unsigned char* const un = DB ? u_first + ((j + 1) & 1) * u_bytes : u_first;
+    unsigned char* const wn = DB ? wl_first + ((j + 1) & 1) * (64 * wstride) : wl_first;
+    if (DB) {
+      u = u_first + (j & 1) * u_bytes;
+      wl = wl_first + (j & 1) * (64 * wstride);
+    }
     R2_STAMP();
     if (!last) load_w(j + 1);                           // in flight during the MFMA loop
     if (DEEP) {
@@ -266,27 +301,44 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
       sh[m] = *(const f32x4*)(ss + j * 128 + 64 + m * 16 + 4 * q);
     }
     auto stage_sp = [&](int n) {
-      unsigned char* ot = ob + (OT > 1 ? n : 0) * (16 * urow);
+      // DB: row (frame + halo) of the next u buffer, in u's own swizzle; frames >= T keep their zeros
+      unsigned char* ot = DB ? un + soff[n] : ob + (OT > 1 ? n : 0) * (16 * urow) + f * urow;
+      const bool f_ok = !DB || (wv + R2_WAVES * n) * 16 + f < T;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int co = m * 16 + 4 * q;
         f32x4 v = acc[n][m];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = relu_f32(v[e]);
         v = v * sc[m] + sh[m];
         const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        if (co < wp) *(bf16x4*)(ot + f * urow + (((co >> 3) ^ (f & swz_mask)) << 4) + (co & 7) * 2) = o;
+        if (co < wp && f_ok)
+          *(bf16x4*)(ot + (DB ? smx[m] : (((co >> 3) ^ (f & swz_mask)) << 4) + (co & 7) * 2)) = o;
       }
     };
     auto drain_sp = [&](int n) {
       const unsigned char* ot = ob + (OT > 1 ? n : 0) * (16 * urow);
+      // all staged chunks of the tile are read first (valid addresses for every lane), so that one LDS round trip is
+      // exposed per tile and not one per item behind its branch
+      u32x4 spv[NI];
+      unsigned char* up[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const u32x4 sp = *(const u32x4*)(ot + ooff[i]);
+        up[i] = un + uoff[n][i];
+        spv[i] = DB ? *(const u32x4*)up[i] : *(const u32x4*)(ot + ooff[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(spv[i]));
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = (wv + R2_WAVES * n) * 16 + irow[i];
+        const u32x4 sp = spv[i];
         if (item_ok(n, i)) {
-          const int r = (wv + R2_WAVES * n) * 16 + irow[i];
-          if (r >= st_lo && r < st_hi) *(u32x4*)(yb + r * a.ld + j * wp + ich[i] * 8) = sp;
-          if (!last) xs[(j + 1) & 1][n][i] = add_bf16x8(xs[(j + 1) & 1][n][i], sp);
+          if (r >= st_lo && r < st_hi) *(u32x4*)((unsigned char*)(yb + j * wp) + yoff[n][i]) = sp;
+          if (!last) {
+            xs[(j + 1) & 1][n][i] = add_bf16x8(xs[(j + 1) & 1][n][i], sp);
+            if (DB) *(u32x4*)up[i] = xs[(j + 1) & 1][n][i];     // u_{j+1} = x_{j+1} + sp_j, in place
+          }
         }
       }
     };
@@ -317,21 +369,28 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
     R2_STAMP();
     // LDS-only barriers: waves exchange data through LDS alone, so only the LDS counter is drained; a full
     // __syncthreads() would also wait (vmcnt(0)) for this step's output stores and the prefetches in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves done reading u and the weights
-    R2_STAMP();
-    if (!last) {
-      write_u((j + 1) & 1);
-      store_w();
+    if (DB) {
+      if (!last) store_w(wn);
+      R2_STAMP();
+      R2_STAMP();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves done reading u and the weights
+      R2_STAMP();
+      if (!last) {
+        write_u((j + 1) & 1);
+        store_w(wl);
+      }
+      R2_STAMP();
     }
-    R2_STAMP();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
-int r2_smem_bytes(int t_max, int wp, int halo, int k_pad) {
+int r2_smem_bytes(int t_max, int wp, int halo, int k_pad, bool db = false) {
   t_max = t_max < R2_MAX_T ? t_max : R2_MAX_T;
   const int u_rows = (t_max + 15) / 16 * 16 + 2 * halo;
   const int ot = 3;                                     // sp staging tiles per wave (kernel: OT)
+  if (db) return 2 * ((u_rows * wp * 2 + 255) & ~255) + 2 * 64 * k_pad * 2 + R2_STEPS * 128 * 4;
   return ((u_rows * wp * 2 + 255) & ~255) + 64 * k_pad * 2 + R2_WAVES * ot * 16 * wp * 2 + R2_STEPS * 128 * 4;
 }
 
@@ -498,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void res2_wide_kernel(Res2Args a) {
             if (n < ntw) {
               f32x4 v0 = acc[n][2 * pp], v1 = acc[n][2 * pp + 1];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+              for (int e = 0; e < 4; ++e) { v0[e] = relu_f32(v0[e]); v1[e] = relu_f32(v1[e]); }
               v0 = v0 * sc0 + sh0;
               v1 = v1 * sc1 + sh1;
               const bf16x8 o = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
@@ -583,7 +642,7 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   }
   SUGAR_CHECK_ARG(a.seg_inner >= 16, "res2: halo %d leaves no room for time segments", halo);
   const int nseg_max = t_max <= a.max_t ? 1 : (int)ceil_div(t_max, a.seg_inner);
-  SUGAR_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && (int64_t)R2_MAX_T * ld < (1ll << 31),
+  SUGAR_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && (int64_t)(R2_MAX_T + 16) * ld < (1ll << 30),
                   "res2: activations must be 16-byte aligned with ld %% 8 == 0 (ld %d)", ld);
   if (wp > 64) {       // (this kernel on 64-channel groups: 0.149 vs 0.129 ms per step for res2_chain_kernel)
     const int subm = r2_wide_subm(t_max, wp, halo, a.k_pad);
@@ -602,18 +661,21 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
     SUGAR_LAUNCH_CHECK();
     return SUGAR_OK;
   }
-  const int smem = r2_smem_bytes(t_max < a.max_t ? t_max : a.max_t, wp, halo, a.k_pad);   // (a segment holds <= max_t frames)
+  const int t_wg = t_max < a.max_t ? t_max : a.max_t;    // (a segment holds <= max_t frames)
+  const int smem_db = r2_smem_bytes(t_wg, wp, halo, a.k_pad, true);
+  const bool db = smem_db <= 160 * 1024 && !tune_get(TUNE_RES2_NO_DB);
+  const int smem = db ? smem_db : r2_smem_bytes(t_wg, wp, halo, a.k_pad);
   SUGAR_CHECK_ARG(smem <= 160 * 1024 && a.k_pad <= 320, "res2: tile does not fit LDS (%d bytes)", smem);
   const int mt = (wp + 15) / 16;
   const bool w3 = a.k_pad <= 192;
-#define R2_CASE(M, TP, WR)                                                                                     \
+#define R2_CASE(M, TP, WR, D)                                                                                  \
   {                                                                                                            \
-    static OptInMask opted{0};                                                                       \
-    if (int rc = lds_opt_in((const void*)res2_chain_kernel<M, TP, WR>, 160 * 1024, &opted)) return rc;         \
-    hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR>), dim3(B, nseg_max), dim3(512), smem, s, a);                        \
+    static OptInMask opted{0};                                                                                 \
+    if (int rc = lds_opt_in((const void*)res2_chain_kernel<M, TP, WR, D>, 160 * 1024, &opted)) return rc;      \
+    hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR, D>), dim3(B, nseg_max), dim3(512), smem, s, a);           \
   }
 #define R2_CASE_W(M, TP) \
-  if (w3) R2_CASE(M, TP, 3) else R2_CASE(M, TP, 5)
+  if (w3 && db) R2_CASE(M, TP, 3, true) else if (w3) R2_CASE(M, TP, 3, false) else if (db) R2_CASE(M, TP, 5, true) else R2_CASE(M, TP, 5, false)
   switch (mt) {
     case 1: R2_CASE_W(1, 3) break;
     case 2: R2_CASE_W(2, 3) break;

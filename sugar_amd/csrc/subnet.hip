@@ -73,8 +73,9 @@ struct Prof {
 
 // ---- tunables: environment read once, then atomics ----
 static const char* kTuneNames[TUNE_COUNT] = {"gemm_wreg_min_r", "gemm_uniform", "gemm_no_pingpong", "generic_res2",
-                                             "res2_max_t", "generic_layer1", "gemm_no_persist", "gemm_no_quad"};
-static const int64_t kTuneDefaults[TUNE_COUNT] = {19200, 0, 0, 0, 0, 0, 0, 0};
+                                             "res2_max_t", "generic_layer1", "gemm_no_persist", "gemm_no_quad",
+                                             "res2_no_db"};
+static const int64_t kTuneDefaults[TUNE_COUNT] = {19200, 0, 0, 0, 0, 0, 0, 0, 0};
 static std::atomic<int64_t> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 

@@ -453,6 +453,11 @@ def test_res2_time_segments_are_bit_identical(name, meta, supernet):
         with _lib.tuned(res2_max_t={None: 384, "auto": 0}.get(cap) if cap in (None, "auto") else int(cap)):   # few-utterance rule
             outs[cap] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
             outs[cap].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
-    for cap in ("256", "160", "auto"):
+    # the kernel without the double-buffered u tile (two barriers per step, staging tiles of its own): same bytes
+    for cap, v in (("whole/no_db", 384), ("160/no_db", 160)):
+        with _lib.tuned(res2_max_t=v, res2_no_db=1):
+            outs[cap] = [sub.tap(feats, row_off, len(frames), R, max(frames), 2 + 4 * i)[0].clone() for i in range(depth)]
+            outs[cap].append(sub.tap(feats, row_off, len(frames), R, max(frames), 101)[1].clone())
+    for cap in ("256", "160", "auto", "whole/no_db", "160/no_db"):
         for i in range(depth + 1):
             assert torch.equal(outs[None][i], outs[cap][i]), (name, cap, i)
