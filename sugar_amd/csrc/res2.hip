@@ -194,6 +194,28 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
     smx[m] = (((co >> 3) ^ (srow & swz_mask)) << 4) + (co & 7) * 2;
     asm volatile("" : "+v"(smx[m]));
   }
+  // fragment addresses of the K loop (see load_frags): boff[ks] = this lane's row (frame f + the tap's shift) and
+  // swizzled chunk of k-step ks inside a u buffer for a tile at row 0, aoff0 / aoff1 = its weight row and swizzled
+  // chunk in even / odd k-steps, tbase[n] = the wave-uniform row base of tile n
+  constexpr int NKS = WREG == 3 ? 6 : 10;               // k_pad <= 192 / 320
+  int boff[NKS], tbase[R2_TPW];
+  {
+    const int inv_wp_ = (65536 + wp - 1) / wp;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int c = 4 * ks + q;                         // this lane's K chunk
+      const int tap = (c * 8 * inv_wp_) >> 16, ci = c * 8 - tap * wp;   // == c*8 / wp, % wp  (c*8 < 1024)
+      const bool kpad = tap >= a.ktaps || ks >= nks;    // K padding: weights are zero, read any valid row
+      const int row = f + halo + (kpad ? 0 : (tap - ctr) * a.dil);
+      boff[ks] = row * urow + (((kpad ? 0 : (ci >> 3)) ^ (row & swz_mask)) << 4);
+      asm volatile("" : "+v"(boff[ks]));
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < R2_TPW; ++n)
+    tbase[n] = __builtin_amdgcn_readfirstlane((n < ntw ? (wv + R2_WAVES * n) * 16 : 0) * urow);
+  int aoff0 = f * wstride + ((q ^ (f & 7)) << 4), aoff1 = f * wstride + (((4 + q) ^ (f & 7)) << 4);
+  asm volatile("" : "+v"(aoff0), "+v"(aoff1));
   auto item_ok = [&](int n, int i) { return n < ntw && irow[i] < 16 && (wv + R2_WAVES * n) * 16 + irow[i] < T; };
   auto load_x = [&](int j, int buf) {
 #pragma unroll
@@ -215,7 +237,6 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
         if (item_ok(n, i)) *(u32x4*)(u + uoff[n][i]) = xs[buf][n][i];
   };
 
-  const int inv_wp = (65536 + wp - 1) / wp;
   load_w(0);
   load_x(0, 0);                                         // u_0 = x_0
   if (DEEP) load_x(1, 1);
@@ -252,24 +273,15 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
     R2_STAMP();
 
     // K loop, fragments of k-step ks+1 read while the MFMAs of ks run (nks is even: k_pad % 64 == 0).  Tiles past
-    // ntw read a clamped (valid) row and their MFMAs are skipped.
-    int ks_ld = 0;
-    auto load_frags = [&](bf16x8 (&af)[MT], bf16x8 (&bf)[R2_TPW]) {
-      const int c = 4 * ks_ld + q;                      // this lane's K chunk
-      const int tap = (c * 8 * inv_wp) >> 16, ci = c * 8 - tap * wp;   // == c*8 / wp, % wp  (c*8 < 1024)
-      const bool kpad = tap >= a.ktaps || ks_ld >= nks; // K padding: weights are zero, read any valid row
-      const int roff = halo + (kpad ? 0 : (tap - ctr) * a.dil);
-      const int cch = kpad ? 0 : (ci >> 3);
-      const int cw = ks_ld < nks ? c : q;               // one step past the end: any valid chunk, never consumed
+    // ntw read a clamped (valid) row and their MFMAs are skipped.  Every address is a pinned per-lane offset (aoff /
+    // boff above) + a wave-uniform term + an immediate: computed afresh per k-step (tap = chunk / wp, row * urow,
+    // the swizzles) the loop spent more VALU time on 32-bit multiplies than the MFMAs take.
+    auto load_frags = [&](int ks, bf16x8 (&af)[MT], bf16x8 (&bf)[R2_TPW]) {   // ks: compile-time after unrolling
+      const unsigned char* ap = wl + ((ks & 1) ? aoff1 : aoff0) + (ks >> 1) * 128;
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        af[m] = *(const bf16x8*)(wl + (m * 16 + f) * wstride + (((cw & ~7) | ((cw & 7) ^ (f & 7))) << 4));
+      for (int m = 0; m < MT; ++m) af[m] = *(const bf16x8*)(ap + m * 16 * wstride);
 #pragma unroll
-      for (int n = 0; n < R2_TPW; ++n) {
-        const int row = (n < ntw ? (wv + R2_WAVES * n) * 16 : 0) + f + roff;
-        bf[n] = *(const bf16x8*)(u + row * urow + ((cch ^ (row & swz_mask)) << 4));
-      }
-      ++ks_ld;
+      for (int n = 0; n < R2_TPW; ++n) bf[n] = *(const bf16x8*)(u + boff[ks] + tbase[n]);
     };
     auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[R2_TPW]) {
 #pragma unroll
@@ -281,12 +293,15 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
     };
     {
       bf16x8 af0[MT], bf0[R2_TPW], af1[MT], bf1[R2_TPW];
-      load_frags(af0, bf0);
-      for (int ks = 0; ks < nks; ks += 2) {
-        load_frags(af1, bf1);
-        mma(af0, bf0);
-        load_frags(af0, bf0);
-        mma(af1, bf1);
+      load_frags(0, af0, bf0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ks += 2) {
+        if (ks < nks) {                                 // (wave-uniform)
+          load_frags(ks + 1, af1, bf1);
+          mma(af0, bf0);
+          if (ks + 2 < NKS && ks + 2 < nks) load_frags(ks + 2 < NKS ? ks + 2 : 0, af0, bf0);
+          mma(af1, bf1);
+        }
       }
     }
     R2_STAMP();
