@@ -171,9 +171,10 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
   u32x4 xs[2][R2_TPW][NI];
   // Byte offsets that do not change from step to step, computed once and pinned in registers (recomputed in all 7
   // unrolled epilogues they were a third of the epilogue's VALU time: 24 quarter-rate 32-bit multiplies per step):
-  //   uoff: item (n, i) inside a u buffer;  yoff / xoff: its row and chunk in y / x (without the group's column);
+  //   uoff: item (n, i) inside a u buffer;  xoff: its row and chunk in x and y (without the group's column; the item's
+  //   own row where it has one, else a valid row: loads are unconditional, stores masked);
   //   soff / smx: the MFMA-layout rows and chunk slots stage_sp writes (DB: in the next u buffer)
-  int uoff[R2_TPW][NI], yoff[R2_TPW][NI], xoff[R2_TPW][NI], soff[R2_TPW], smx[MT];
+  int uoff[R2_TPW][NI], xoff[R2_TPW][NI], soff[R2_TPW], smx[MT];
 #pragma unroll
   for (int n = 0; n < R2_TPW; ++n) {
 #pragma unroll
@@ -181,9 +182,8 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
       const int r = (wv + R2_WAVES * n) * 16 + irow[i];
       const int row = min(r, 16 * NT - 1) + halo;       // (irow 16 = no such item: any row of the buffer, never used)
       uoff[n][i] = row * urow + ((ich[i] ^ (row & swz_mask)) << 4);
-      yoff[n][i] = (r * a.ld + ich[i] * 8) * 2;
       xoff[n][i] = (min((wv + R2_WAVES * n) * 16 + min(irow[i], 15), T - 1) * a.ld + ich[i] * 8) * 2;   // a valid row for every lane
-      asm volatile("" : "+v"(uoff[n][i]), "+v"(yoff[n][i]), "+v"(xoff[n][i]));
+      asm volatile("" : "+v"(uoff[n][i]), "+v"(xoff[n][i]));
     }
     soff[n] = ((wv + R2_WAVES * n) * 16 + f + halo) * urow;
     asm volatile("" : "+v"(soff[n]));
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void res2_chain_kernel(Res2Args a) {
         const int r = (wv + R2_WAVES * n) * 16 + irow[i];
         const u32x4 sp = spv[i];
         if (item_ok(n, i)) {
-          if (r >= st_lo && r < st_hi) *(u32x4*)((unsigned char*)(yb + j * wp) + yoff[n][i]) = sp;
+          if (r >= st_lo && r < st_hi) *(u32x4*)((unsigned char*)(yb + j * wp) + xoff[n][i]) = sp;
           if (!last) {
             xs[(j + 1) & 1][n][i] = add_bf16x8(xs[(j + 1) & 1][n][i], sp);
             if (DB) *(u32x4*)up[i] = xs[(j + 1) & 1][n][i];     // u_{j+1} = x_{j+1} + sp_j, in place
@@ -678,7 +678,7 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
   }
   const int t_wg = t_max < a.max_t ? t_max : a.max_t;    // (a segment holds <= max_t frames)
   const int smem_db = r2_smem_bytes(t_wg, wp, halo, a.k_pad, true);
-  const bool db = smem_db <= 160 * 1024 && !tune_get(TUNE_RES2_NO_DB);
+  const bool db = smem_db <= 160 * 1024 && a.k_pad <= 192 && !tune_get(TUNE_RES2_NO_DB);   // (5 taps: the DB form spills)
   const int smem = db ? smem_db : r2_smem_bytes(t_wg, wp, halo, a.k_pad);
   SUGAR_CHECK_ARG(smem <= 160 * 1024 && a.k_pad <= 320, "res2: tile does not fit LDS (%d bytes)", smem);
   const int mt = (wp + 15) / 16;
@@ -690,7 +690,7 @@ int launch_res2_chain(const ConvLayer* steps, const void* d_x, void* d_y, int ld
     hipLaunchKernelGGL((res2_chain_kernel<M, TP, WR, D>), dim3(B, nseg_max), dim3(512), smem, s, a);           \
   }
 #define R2_CASE_W(M, TP) \
-  if (w3 && db) R2_CASE(M, TP, 3, true) else if (w3) R2_CASE(M, TP, 3, false) else if (db) R2_CASE(M, TP, 5, true) else R2_CASE(M, TP, 5, false)
+  if (w3 && db) R2_CASE(M, TP, 3, true) else if (w3) R2_CASE(M, TP, 3, false) else R2_CASE(M, TP, 5, false)
   switch (mt) {
     case 1: R2_CASE_W(1, 3) break;
     case 2: R2_CASE_W(2, 3) break;
