@@ -1,0 +1,17 @@
+set -e
+VARS="${VARS:-old new}"
+N="${N:-3}"
+for i in $(seq $N); do
+for v in $VARS; do
+  cp tools/libsugar_$v.so sugar_amd/libsugar_amd.so
+  echo "== $v $i"
+  timeout -k 10 120 python3 bench.py --workload ${WL:-base256} --steps 40 --warmup 10 --no-cpu-baseline --no-pipelined --stages 2>&1 | python3 -c "
+import sys,json
+for l in sys.stdin:
+    l=l.strip()
+    if l.startswith('{'):
+        d=json.loads(l); print(d['ms_per_step'], ' '.join('%s %.4f'%(k[:6],v) for k,v in d.get('stages_ms',{}).items()))
+"
+done
+done
+cp tools/libsugar_new.so sugar_amd/libsugar_amd.so
