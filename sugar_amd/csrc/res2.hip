@@ -503,7 +503,12 @@ __global__ __launch_bounds__(512, 2) void res2_wide_kernel(Res2Args a) {
       }
   };
 
-  const int inv_wp = (65536 + wp - 1) / wp;
+  // per-lane offsets of the K loop's fragment reads (load_frags) and the wave-uniform row bases of the tiles
+  int aoff = f * wstride + ((q ^ (f & 7)) << 4), fh = f + halo, fhu = (f + halo) * urow;
+  asm volatile("" : "+v"(aoff), "+v"(fh), "+v"(fhu));
+  int tbase[TPW];
+#pragma unroll
+  for (int n = 0; n < TPW; ++n) tbase[n] = __builtin_amdgcn_readfirstlane((n < ntw ? (wv + R2_WAVES * n) * 16 : 0) * urow);
   load_w(0, 0);
   load_x(0);                                            // u_0 = x_0
   __syncthreads();                                      // zero fill complete before the first u write
@@ -524,23 +529,24 @@ __global__ __launch_bounds__(512, 2) void res2_wide_kernel(Res2Args a) {
         for (int n = 0; n < TPW; ++n)
 #pragma unroll
           for (int m = 0; m < SUBM; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int ks_ld = 0;
+        // Fragment addresses without per-lane multiplies (they cost the K loop more issue time than its MFMAs): wp is a
+        // multiple of 32 here, so the 4 chunks of a k-step lie in ONE tap -- tap = ks / npg and the chunk 4 (ks % npg) + q
+        // are kept as wave-uniform counters, and a lane adds its pinned offsets (aoff, fhu, fh) to scalar terms.
+        int ks_ld = 0, tap_s = 0, kin_s = 0;
         auto load_frags = [&](bf16x8 (&af)[SUBM], bf16x8 (&bf)[TPW]) {
-          const int c = 4 * ks_ld + q;                    // this lane's K chunk
-          const int tap = (c * 8 * inv_wp) >> 16, ci = c * 8 - tap * wp;
-          const bool kpad = tap >= a.ktaps || ks_ld >= nks;
-          const int roff = halo + (kpad ? 0 : (tap - ctr) * a.dil);
-          const int cch = kpad ? 0 : (ci >> 3);
-          const int cw = ks_ld < nks ? c : q;
+          const bool kpad = tap_s >= a.ktaps || ks_ld >= nks;   // K padding: weights are zero, read any valid row
+          const int shift = kpad ? 0 : (tap_s - ctr) * a.dil;   // the tap's row shift
+          const int c4 = kpad ? 0 : 4 * kin_s;                  // this k-step's first chunk among the tap's channels
+          const int kw = ks_ld < nks ? ks_ld : 0;               // one step past the end: any valid chunk, never consumed
+          const unsigned char* ap = wl + (aoff ^ ((kw & 1) << 6)) + (kw >> 1) * 128;
 #pragma unroll
-          for (int m = 0; m < SUBM; ++m)
-            af[m] = *(const bf16x8*)(wl + (m * 16 + f) * wstride + (((cw & ~7) | ((cw & 7) ^ (f & 7))) << 4));
+          for (int m = 0; m < SUBM; ++m) af[m] = *(const bf16x8*)(ap + m * 16 * wstride);
+          const int t = (fh + shift) & swz_mask;
+          const unsigned char* bp = u + fhu + (((q ^ t) ^ c4) << 4) + shift * urow;
 #pragma unroll
-          for (int n = 0; n < TPW; ++n) {
-            const int row = (n < ntw ? (wv + R2_WAVES * n) * 16 : 0) + f + roff;
-            bf[n] = *(const bf16x8*)(u + row * urow + ((cch ^ (row & swz_mask)) << 4));
-          }
+          for (int n = 0; n < TPW; ++n) bf[n] = *(const bf16x8*)(bp + tbase[n]);
           ++ks_ld;
+          if (++kin_s == npg) { kin_s = 0; ++tap_s; }
         };
         auto mma = [&](const bf16x8 (&af)[SUBM], const bf16x8 (&bf)[TPW]) {
 #pragma unroll
