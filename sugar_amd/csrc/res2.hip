@@ -8,14 +8,19 @@
 // Here one workgroup (8 waves) owns one utterance for the whole chain:
 //   * u = x_j + sp_{j-1} lives in LDS as [frame + halo][w] bf16 (zero halo rows = the conv's "same" padding at the
 //     utterance's true ends), chunk-swizzled so the shifted fragment reads of every tap are bank-conflict free;
-//   * each wave owns up to 5 tiles of 16 frames; D[channel][frame] = sum over (tap, ci) W[co][tap*w+ci] u[frame+off][ci]
+//   * each wave owns up to 3 tiles of 16 frames; D[channel][frame] = sum over (tap, ci) W[co][tap*w+ci] u[frame+off][ci]
 //     with v_mfma_f32_16x16x32_bf16; the weights of step j+1 are prefetched into registers during step j and
 //     staged in LDS with the same XOR swizzle; the folded-BN vectors of all 7 steps sit in LDS;
-//   * global traffic is row-contiguous, 16 bytes per lane: the MFMA epilogue (ReLU -> folded BN) drops sp_j of one
-//     frame tile into a wave-private 2 KB LDS tile, the wave reads it back as whole 16-byte chunks, stores them to the
-//     output slice and adds the x_{j+1} chunks (prefetched one step ahead in the same layout) to form u_{j+1}.
+//   * global traffic is row-contiguous, 16 bytes per lane: the MFMA epilogue (ReLU -> folded BN) drops sp_j of a
+//     frame tile into LDS in MFMA layout, the wave reads it back as whole 16-byte chunks, stores them to the output
+//     slice and adds the x_{j+1} chunks (prefetched two steps ahead in the same layout) to form u_{j+1}.
 //     In-kernel stamps showed the earlier 8-byte-per-lane loads/stores in MFMA layout (16 half-used lines per
-//     instruction, 37 vector-memory instructions per wave and step) spent 60 % of every step in memory issue.
+//     instruction, 37 vector-memory instructions per wave and step) spent 60 % of every step in memory issue;
+//   * DB form (3-tap panels): u and the weight panel are double-buffered, the staging area of a wave is its own rows of
+//     the next u buffer, u_{j+1} is left there in place: one workgroup barrier per step;
+//   * every address that does not change from step to step is a per-lane offset computed once and pinned in a
+//     register: recomputed per fragment read / per staged item, the address arithmetic (quarter-rate 32-bit
+//     multiplies, swizzles) took more VALU issue time than the step's 72 MFMAs per wave.
 // Utterances longer than the 384 frames one workgroup holds are cut into time segments, one workgroup each: a segment
 // processes its frames plus H = 7 * halo context frames on every side that is not a true utterance end.  Treating the
 // clipped side as zero padding corrupts sp_j within (j + 1) * halo frames of it, i.e. never inside the stored range,
