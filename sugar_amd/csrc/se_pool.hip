@@ -221,7 +221,7 @@ __global__ __launch_bounds__(1024) void se_expand_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ SE apply
-constexpr int APPLY_ROWS = 32;
+constexpr int APPLY_ROWS = 4;     // 256 chunks = one per thread (bf16): 32 rows (8 dependent round trips per thread) ran at 5.9 TB/s, 4 rows at 6.8
 // The block output `out` (a column slice of the catconv input) is not read again before catconv, the running sum S is
 // read by the next block's first_conv right away: `out` goes out with non-temporal stores, so that it does not push S
 // (and the y / mid tensors of the next block) out of the Infinity Cache.  Same job, 256 x 3 s: first_conv 0.165 ->
