@@ -165,6 +165,15 @@ __global__ __launch_bounds__(1024) void se_expand_kernel(const float* __restrict
   float* part = sm + SE_U * se.hid;
   const int b0 = blockIdx.x * SE_U, tid = threadIdx.x, hid = se.hid;
   const int nu = min(SE_U, B - b0);
+  // this thread's first 16 expand weights do not depend on the hidden vector: requested here, their L2 round trip runs
+  // under the one of the shares below instead of behind the barrier
+  const int c = blockIdx.y * SE_CB + (tid & (SE_CB - 1)), kp = tid / SE_CB;
+  const int cl = min(c, se.c_p - 1);
+  const int per = (hid + SE_KP - 1) / SE_KP;
+  const int j0 = kp * per, j1 = min(hid, j0 + per);
+  float w0[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w0[k] = se.w2t[(size_t)min(j0 + k, hid - 1) * se.c_p + cl];
   for (int idx = tid; idx < SE_U * hid; idx += 1024) {
     const int u = idx / hid, j = idx - u * hid;
     float t = 0.f;
@@ -186,17 +195,13 @@ __global__ __launch_bounds__(1024) void se_expand_kernel(const float* __restrict
     hidden[idx] = t;
   }
   __syncthreads();
-  const int c = blockIdx.y * SE_CB + (tid & (SE_CB - 1)), kp = tid / SE_CB;
-  const int cl = min(c, se.c_p - 1);
   float t[SE_U];
 #pragma unroll
   for (int u = 0; u < SE_U; ++u) t[u] = 0.f;
-  const int per = (hid + SE_KP - 1) / SE_KP;
-  const int j0 = kp * per, j1 = min(hid, j0 + per);
   for (int jb = j0; jb < j1; jb += 16) {
     float w[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) w[k] = se.w2t[(size_t)min(jb + k, hid - 1) * se.c_p + cl];
+    for (int k = 0; k < 16; ++k) w[k] = jb == j0 ? w0[k] : se.w2t[(size_t)min(jb + k, hid - 1) * se.c_p + cl];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const float wk = (jb + k < j1) ? w[k] : 0.f;
