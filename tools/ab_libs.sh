@@ -1,3 +1,6 @@
+# Same-job A/B of library builds: tools/libsugar_<name>.so (copies of sugar_amd/libsugar_amd.so built from the trees to
+# compare) are swapped in turn under the same bench command, N alternations, on ONE box -- the boxes of the pool differ
+# by ~3 % with the same binary.  VARS="old new" N=3 WL=base256 bash tools/ab_libs.sh   (run through gpurun)
 set -e
 VARS="${VARS:-old new}"
 N="${N:-3}"
