@@ -3,12 +3,15 @@
 bench.py -- speaker embeddings/sec (3 s @ 16 kHz) of the MI355X-native EfficientTDNN extraction path.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload base256|largest256|wide256] [--precision bf16|fp32]
+    python bench.py --workload largest --global-batch 512 [--gpus N]      # BASELINE configs[2] as written: strong scaling
 
 One step = one pass of the hot path (waveforms already resident in HBM -> fused fbank -> TDNN -> L2-normalised
 embeddings) over one batch of 256 synthetic 3 s utterances per GPU.  N > 1: launched by torch.distributed.run, one
 rank per GPU, utterance batches sharded across ranks (weak scaling, no data-path collective inside the network);
 the only exchange step is the all-gather of the [256, 192] embeddings of each step (RCCL over xGMI), issued
-asynchronously and completed inside the timed region.
+asynchronously and completed inside the timed region.  --global-batch G splits ONE batch of G utterances evenly over the
+ranks instead (G / N per GPU, "scaling": "strong"): BASELINE configs[2] is the Largest subnet at a global batch of 512
+on 1 / 2 / 4 / 8 GPUs; on one GPU `--workload largest --global-batch 512|256|128|64` measures the per-GPU share of each.
 
 Rank 0 prints ONE JSON line (see the driver contract); it carries
   roofline     : the dominant kernel = the catconv GEMM launch (49 % of the MACs): algorithmic FLOPs per
@@ -36,6 +39,8 @@ WORKLOADS = {
     "base128": ("BASE", 128, 48000, "tdnn8m2g"),     # diagnostic: 3.5 rounds of catconv tiles
     "base1": ("BASE", 1, 48000, "tdnn8m2g"),         # diagnostic: one utterance, the latency floor of ~35 dependent kernels
     "wide256": ((3, [1024] * 4, [5] * 4, 1536), 256, 48000, "tdnn16m4g"),
+    "largest": ("LARGEST", 512, 48000, "tdnn8m2g"),   # configs[2]: the batch is GLOBAL (--global-batch, default 512)
+    "base": ("BASE", 256, 48000, "tdnn8m2g"),         # with --global-batch: Base at a global batch split over the ranks
 }
 SUPERNETS = {"tdnn8m2g": (80, 192, 4, 512, 5, 1536), "tdnn16m4g": (80, 192, 3, 1024, 5, 1536)}   # supernet_shapes arguments
 PREHEAT_STEPS = 30   # untimed passes at set-up, before the W warm-up steps: the clocks of an idle MI355X take ~25 ms of
@@ -109,6 +114,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="base256", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="strong scaling: ONE batch of this many utterances split evenly over the ranks (per-GPU batch = "
+                         "G / N); default for --workload largest / base: 512 / 256.  Without it the per-GPU batch is "
+                         "the workload's and the global batch grows with N (weak scaling)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the timed steps alternate over (each with its own workspace).  1 (default) keeps "
                          "the per-kernel roofline clean; the 2-stream rate (consecutive batches overlapping on the GPU) "
@@ -151,6 +160,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg, B, L, family = WORKLOADS[args.workload]
+    strong = args.global_batch is not None or args.workload in ("largest", "base")
+    if strong:
+        G = args.global_batch if args.global_batch is not None else B
+        if G % world or G < world:
+            sys.exit("bench.py: --global-batch %d does not split evenly over %d ranks" % (G, world))
+        B = G // world
     config = getattr(layout, cfg) if isinstance(cfg, str) else cfg
     sup = getattr(sugar_amd, family)()
     sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(*SUPERNETS[family]), seed=0))
@@ -166,11 +181,24 @@ def main():
 
     gathered = [torch.empty(world * B, 192, device=dev) for _ in range(2)] if world > 1 else None
 
+    # rehearsal backend (gloo): the exchange is staged through pinned host buffers by hand -- torch's gloo path for CUDA
+    # tensors synchronises and stages on streams of its own, and with steps alternating over two side streams that
+    # cost 4.6 s per step in round 2's rehearsal (profiles/bench_r02_2rank_gloo_rehearsal.json, "pipelined" leg)
+    host_in = [torch.empty(B, 192).pin_memory() for _ in range(2)] if world > 1 and backend != "nccl" else None
+    host_out = [torch.empty(world * B, 192).pin_memory() for _ in range(2)] if world > 1 and backend != "nccl" else None
+
+    class _Done:
+        def wait(self):
+            return True
+
     def all_gather(i, emb):
         if backend == "nccl":
             return dist.all_gather_into_tensor(gathered[i & 1], emb, async_op=True)
-        torch.cuda.current_stream().synchronize()          # gloo reads the tensor from the host side
-        return dist.all_gather(list(gathered[i & 1].view(world, B, 192).unbind(0)), emb, async_op=True)
+        host_in[i & 1].copy_(emb, non_blocking=True)
+        torch.cuda.current_stream().synchronize()          # gloo moves host memory
+        dist.all_gather_into_tensor(host_out[i & 1], host_in[i & 1])
+        gathered[i & 1].copy_(host_out[i & 1], non_blocking=True)
+        return _Done()
 
     lanes = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))]
 
@@ -210,10 +238,19 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_read()
     _lib.profile_enable(0)
+    ranks_seen = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # evidence for the scaling record: which ranks took part, on which cards, what the last all-gather delivered
+        # (row 0 of every rank's block of the last step's embeddings must be a unit vector from that rank)
+        last = gathered[(args.steps - 1) & 1].view(world, B, 192)[:, 0].norm(dim=1)
+        mine = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev),
+                "pci_bus": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
+                "gathered_row_norms": [round(float(x), 4) for x in last.cpu()]}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
 
     # after the timed region: the same K steps alternating over two streams (HBM-bound kernels of one batch under
     # the MFMA-bound kernels of the next); reported beside `value`, never as `value`
@@ -290,13 +327,14 @@ def main():
             "unit": "embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s: EfficientTDNN subnet %s, %d x 3 s (48000-sample) utterances per GPU, "
                                    "waveform -> fbank -> TDNN -> L2-normalised 192-d embedding"
                                    % (args.workload, layout.config_name(config), B),
                        "per_gpu_batch": B, "global_batch": world * B, "frames_per_utt": T,
                        "parallelism": "utterance-sharded x%d, all-gather of embeddings (%s)" % (world, backend),
+                       "world_size": world, "collective_backend": backend if world > 1 else None,
                        "streams": len(lanes), "preheat_steps": args.preheat,
                        "weights": "deterministic synthetic (sugar_amd/synth.py)"},
             "roofline": {"kernel": "%s catconv launch [%d frames x K %d -> %d]"
@@ -314,6 +352,8 @@ def main():
             out["stage_roofline"] = stage_roof
         if pipelined:
             out["pipelined"] = pipelined
+        if ranks_seen:
+            out["ranks"] = ranks_seen
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config, SUPERNETS[family])
         print(json.dumps(out))

@@ -219,6 +219,15 @@ int sugar_cosine_trials(const float* d_vec, int dim, const int32_t* d_seg_off, i
                         const int32_t* d_enroll, const int32_t* d_test, int64_t n_trials,
                         float* d_scores, void* stream);
 
+/* Replaces: the same loop over calculate_score(mode="norm2") -- the reference's DEFAULT mode (sugar/scores.py:114,
+ * 141-145): F.pairwise_distance(enroll[n, D, 1], test[1, D, m]) broadcasts to [n, D, m] and takes the 2-norm of
+ * (x1 - x2 + 1e-6) over the LAST axis (the m test segments), so
+ *   score[t] = - mean over (i < n, d < dim) of sqrt( sum over j < m of (e[i][d] - t[j][d] + 1e-6)^2 ).
+ * Arguments as sugar_cosine_trials. */
+int sugar_norm2_trials(const float* d_vec, int dim, const int32_t* d_seg_off, int n_utts,
+                       const int32_t* d_enroll, const int32_t* d_test, int64_t n_trials,
+                       float* d_scores, void* stream);
+
 /* ---- adaptive score normalisation back-end -----------------------------------------
  * Replaces: score_cohorts (sugar/scores.py:77-111): d_out[u][m] = mean over utterance u's segment vectors of
  * F.cosine_similarity(segment, cohort m) (eps 1e-8).  d_vec / d_seg_off as in sugar_cosine_trials,

@@ -305,9 +305,26 @@ def cosine_score(enroll: torch.Tensor, test: torch.Tensor) -> float:
     return d.mean().item()
 
 
-def score_trials(enroll_idx, test_idx, vectors) -> np.ndarray:
-    """score_trials loop (sugar/scores.py:188-214) on integer utterance ids; vectors: list of [n_i, D] tensors."""
-    return np.array([cosine_score(vectors[int(a)], vectors[int(b)]) for a, b in zip(enroll_idx, test_idx)])
+def norm2_score(enroll: torch.Tensor, test: torch.Tensor) -> float:
+    """
+    calculate_score(mode='norm2') (sugar/scores.py:141-145) -- the reference's DEFAULT mode, restated as the arithmetic
+    it actually performs: F.pairwise_distance(enroll[n, D, 1], test[1, D, m]) broadcasts to [n, D, m] and takes the
+    2-norm of (x1 - x2 + 1e-6) over the LAST axis, i.e. over the m test segments (not over D), giving [n, D]; the score
+    is minus the mean of that.  (For m = 1 this is minus the mean absolute difference, offset by the eps.)
+    """
+    e = enroll.cpu().float().unsqueeze(2)                   # [n, D, 1]
+    t = test.cpu().float().t().unsqueeze(0)                 # [1, D, m]
+    d = (e - t + 1e-6).pow(2).sum(dim=2).sqrt()             # [n, D]
+    return -d.mean().item()
+
+
+def score_trials(enroll_idx, test_idx, vectors, mode="cosine") -> np.ndarray:
+    """score_trials loop (sugar/scores.py:188-214) on integer utterance ids; vectors: list of [n_i, D] tensors.
+    mode: "cosine", "norm2" or a list of them (then one column per mode, :151-152)."""
+    fn = {"cosine": cosine_score, "norm2": norm2_score}
+    if isinstance(mode, list):
+        return np.array([[fn[m](vectors[int(a)], vectors[int(b)]) for m in mode] for a, b in zip(enroll_idx, test_idx)])
+    return np.array([fn[mode](vectors[int(a)], vectors[int(b)]) for a, b in zip(enroll_idx, test_idx)])
 
 
 def count_macs(config, T: int) -> float:

@@ -1129,7 +1129,7 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // (the persistent 256 x 256 kernel on these shapes: 0.208 / 0.192 ms per step for first / last conv against
       // 0.170 / 0.158 here -- 8 k-tiles per tile leave its epilogue a third of the tile; on the quadrant schedule, whose
       // DMA stream runs across tiles, 0.180 / 0.169 against 0.167 / 0.155)
-      if (R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) {
+      if (L.wfrag && R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) {
         a.wfrag = (const bf16*)L.wfrag;
         return launch_wreg<8, 2, 4>(a, s);
       }

@@ -383,9 +383,12 @@ static bool layer1_as_tap_gemm(const SugarSubnet* n) {
   return !tune_get(TUNE_GENERIC_LAYER1) && gemm_taps_eligible(n->layer1, n->in_feats, n->dtype);
 }
 
-// feats == nullptr: the front-end has already written the padded copy w.featp (sugar_embed_fwd)
+// feats == nullptr: the front-end has already written the padded copy w.featp (sugar_embed_fwd).
+// l1_taps: layer1_as_tap_gemm(n), read ONCE per call by the entry point (a concurrent sugar_tune_set may not land
+// between the front-end's choice of layout and this function's choice of kernel).
 static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* row_off, int B, int64_t R, int t_max,
-                        const Workspace& w, float* d_emb, int normalize, int tap, float* tap_out, hipStream_t s) {
+                        const Workspace& w, float* d_emb, int normalize, int tap, float* tap_out, hipStream_t s,
+                        bool l1_taps) {
   const int dt = n->dtype;
   const int64_t esz = dt == SUGAR_F32 ? 4 : 2;
   int rc;
@@ -410,7 +413,7 @@ static int tdnn_forward(const SugarSubnet* n, const void* feats, const int32_t* 
   io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
   {
     Prof p(SUGAR_STAGE_LAYER1, s);
-    if (layer1_as_tap_gemm(n)) {
+    if (l1_taps) {
       if (feats && (rc = launch_pad_rows(n->layer1, feats, w.featp, row_off, B, R, t_max, s))) return rc;
       // feats == nullptr: the fused front-end has written the padded layout AND its output-row map
       rc = launch_gemm_taps(n->layer1, w.featp, w.orow, w.S, n->c0p, row_off, B, R, t_max, s, feats == nullptr);
@@ -666,7 +669,8 @@ int sugar_tdnn_fwd(const SugarSubnet* net, const void* d_feats, const int32_t* d
   if (rc) return rc;
   SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
-  return tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, (hipStream_t)stream);
+  return tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, (hipStream_t)stream,
+                      layer1_as_tap_gemm(net));
 }
 
 int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d_wav_off, const int32_t* d_wav_len,
@@ -688,7 +692,7 @@ int sugar_embed_fwd(const SugarSubnet* net, const float* d_wav, const int64_t* d
                            padded ? gemm_taps_orow_ints(net->layer1, B, R) : 0)))
       return rc;
   }
-  return tdnn_forward(net, padded ? nullptr : w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s);
+  return tdnn_forward(net, padded ? nullptr : w.feats, d_row_off, B, R, t_max, w, d_emb, normalize, -1, nullptr, s, padded);
 }
 
 int sugar_tdnn_recalibrate(SugarSubnet* net, const void* d_feats, const int32_t* d_row_off, int B, int64_t R, int t_max,
@@ -789,7 +793,8 @@ int sugar_tdnn_tap(const SugarSubnet* net, const void* d_feats, const int32_t* d
                   (long long)(rows * C));
   SUGAR_DEVICE_GUARD(net->device);
   const Workspace w = plan(net, B, R, d_workspace);
-  rc = tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, 0, what, d_out, (hipStream_t)stream);
+  rc = tdnn_forward(net, d_feats, d_row_off, B, R, t_max, w, d_emb, 0, what, d_out, (hipStream_t)stream,
+                    layer1_as_tap_gemm(net));
   return rc ? rc : C;
 }
 

@@ -134,6 +134,7 @@ class TDNNSubnet(nn.Module):
         self._device = torch.device("cpu")
         self._bn_dirty = None    # (device index, dtype) of the handle holding recalibrated, not yet synced statistics
         self._bn_batches = 0
+        self._generation = 0     # bumped whenever device pointers handed out earlier become invalid (release, precision)
         # parameters changed (also via a parent's load_state_dict) -> drop the packed device copies
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.release())
         self.eval()
@@ -169,10 +170,19 @@ class TDNNSubnet(nn.Module):
     def set_precision(self, precision):
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision %r not in ['bf16', 'fp32']" % (precision,))
+        if precision != self.precision:
+            self._generation += 1
         self.precision = precision
         return self
 
+    @property
+    def generation(self):
+        """Changes whenever packed weights / workspaces handed out earlier may have been freed or the compute dtype
+        changed: what a captured HIP graph (graphs.GraphedEmbedder) compares before it replays baked-in pointers."""
+        return self._generation
+
     def release(self):
+        self._generation += 1
         for h in self._handles.values():
             _lib.lib().sugar_subnet_destroy(h)
         self._handles = {}

@@ -1,6 +1,7 @@
 """
-Cosine trial scoring with the reference's interface (sugar/scores.py:114-216), computed by one batched HIP
-kernel (sugar_cosine_trials) instead of a per-trial python loop on the CPU.
+Trial scoring with the reference's interface (sugar/scores.py:114-216): modes "cosine", "norm2" (the reference's
+default for calculate_score) and lists of modes, each computed by one batched HIP kernel (sugar_cosine_trials,
+sugar_norm2_trials) instead of a per-trial python loop on the CPU.
 """
 import numpy as np
 import torch
@@ -12,46 +13,60 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def score_pairs(vec, seg_off, enroll_idx, test_idx):
+MODES = ("cosine", "norm2")
+
+
+def _check_mode(mode):
+    """A mode string or a list of them (sugar/scores.py:140, 151); anything else is an error (the reference falls
+    through to an UnboundLocalError there)."""
+    for m in (mode if isinstance(mode, list) else [mode]):
+        if m not in MODES:
+            raise ValueError("scoring mode %r not in %s" % (m, list(MODES)))
+
+
+def score_pairs(vec, seg_off, enroll_idx, test_idx, mode="cosine"):
     """
     vec [n_rows, D] float32 CUDA; seg_off int32 [n_utts+1]; enroll_idx / test_idx int32 [n_trials] (CUDA).
-    Returns float32 CUDA scores [n_trials] = mean of the pairwise cosines of each trial's segment vectors.
+    Returns float32 CUDA scores [n_trials]: "cosine" = mean of the pairwise cosines of each trial's segment vectors
+    (sugar/scores.py:146-150); "norm2" = minus the mean pairwise_distance as the reference calls it (:141-145; the
+    2-norm runs over the test segments, see include/sugar_amd.h).
     """
     if not vec.is_cuda:
         raise _lib.SugarError("sugar_amd runs on an MI355X only: vectors must be CUDA tensors (no CPU fallback)")
+    _check_mode(mode)
     vec = vec.contiguous().float()
     n_trials = int(enroll_idx.numel())
     out = torch.empty(n_trials, dtype=torch.float32, device=vec.device)
-    rc = _lib.lib().sugar_cosine_trials(vec.data_ptr(), vec.shape[1], seg_off.data_ptr(), int(seg_off.numel()) - 1,
-                                        enroll_idx.data_ptr(), test_idx.data_ptr(), n_trials, out.data_ptr(),
-                                        _stream(vec.device))
-    _lib.check(rc, "sugar_cosine_trials")
+    fn = _lib.lib().sugar_cosine_trials if mode == "cosine" else _lib.lib().sugar_norm2_trials
+    rc = fn(vec.data_ptr(), vec.shape[1], seg_off.data_ptr(), int(seg_off.numel()) - 1, enroll_idx.data_ptr(),
+            test_idx.data_ptr(), n_trials, out.data_ptr(), _stream(vec.device))
+    _lib.check(rc, "sugar_%s_trials" % mode)
     return out
 
 
-def calculate_score(enroll_feat, test_feat, mode="cosine"):
-    """sugar/scores.py:114-153, cosine mode: mean over the n x m pairwise cosines -> python float."""
+def calculate_score(enroll_feat, test_feat, mode="norm2"):
+    """sugar/scores.py:114-153: "cosine" = mean over the n x m pairwise cosines, "norm2" (the reference's default) =
+    minus the mean pairwise distance -> python float; a list of modes -> list of floats."""
+    _check_mode(mode)
     if isinstance(mode, list):
         return [calculate_score(enroll_feat, test_feat, m) for m in mode]
-    if mode != "cosine":
-        raise ValueError("only mode='cosine' is on the accelerated path (got %r)" % (mode,))
     dev = enroll_feat.device
     vec = torch.cat([enroll_feat, test_feat.to(dev)], dim=0)
     n, m = enroll_feat.shape[0], test_feat.shape[0]
     seg = torch.tensor([0, n, n + m], dtype=torch.int32, device=dev)
     e = torch.zeros(1, dtype=torch.int32, device=dev)
     t = torch.ones(1, dtype=torch.int32, device=dev)
-    return float(score_pairs(vec, seg, e, t).item())
+    return float(score_pairs(vec, seg, e, t, mode).item())
 
 
 def score_trials(trials, vectors, mode="cosine", n_jobs=4):
     """
     sugar/scores.py:156-216.  trials: iterable of {"label", "enroll", "test"} (VerificationTrials, database.py:314-318);
     vectors: {utterance: Tensor[n_seg, D]} as returned by extract_vectors.
+    mode: "cosine", "norm2" or a list of them (then scores is [n_trials, len(mode)], one column per mode, :175-177).
     Returns (scores float64 ndarray, labels ndarray, [[enroll, test], ...]) like the reference.
     """
-    if mode != "cosine":
-        raise ValueError("only mode='cosine' is on the accelerated path (got %r)" % (mode,))
+    _check_mode(mode)
     matrix = getattr(vectors, "matrix", None)
     if matrix is not None:                       # a VectorTable from extract_vectors: one matrix, offsets on the device
         keys, vec, seg_off, dev = vectors.files, matrix, vectors.seg_off, matrix.device
@@ -64,7 +79,10 @@ def score_trials(trials, vectors, mode="cosine", n_jobs=4):
         vec = torch.cat([vectors[k].reshape(-1, vectors[k].shape[-1]) for k in keys], dim=0)
         seg_off = torch.tensor(seg, dtype=torch.int32, device=dev)
     labels, pairs, e_dev, t_dev = _trial_index(trials, keys, dev)
-    scores = score_pairs(vec, seg_off, e_dev, t_dev)
+    if isinstance(mode, list):
+        scores = torch.stack([score_pairs(vec, seg_off, e_dev, t_dev, m) for m in mode], dim=1)
+    else:
+        scores = score_pairs(vec, seg_off, e_dev, t_dev, mode)
     return scores.double().cpu().numpy(), labels, pairs
 
 

@@ -7,9 +7,11 @@ NAS subnet-evaluation sweep (BASELINE config 5; the loop of tutorials/EfficientT
         batch_forward(train_loader, model)           # BN recalibration, sugar/models/__init__.py:201-242
         eer, dcf = veri_validate(veri_loader, model) # sugar/models/__init__.py:535-595
 
-The reference runs the configs one after another on one GPU.  Here the configs are dealt to the ranks (one process per
-GPU, longest first by multiply-adds, no collective on the data path: every rank embeds the whole evaluation list with
-its own subnets), and on each rank the NEXT subnet is cloned and packed for the GPU on a host thread while the
+The reference runs the configs one after another on one GPU (and, in scripts/train_vox2_veri.py:385-403, strides
+CHECKPOINTS over the GPUs: rank g evaluates models g, g + N, ... over the whole list, no collective).  Here the configs
+are dealt to the ranks the same way (one process per GPU, longest first by multiply-adds, NO collective on the data
+path: every rank embeds the WHOLE evaluation list with its own subnets -- extract_vectors is called un-sharded, whatever
+process group is live), and on each rank the NEXT subnet is cloned and packed for the GPU on a host thread while the
 current one is being evaluated (clone + pack is 8-12 ms of host work against 12-30 ms of GPU work for 4 874
 utterances, tools/clone_bench.py).  The evaluation list is staged on the GPU once (PackedUtterances) and the trial
 index arrays are built once, so a subnet costs its GPU time and little else.  The only exchange is one
@@ -56,17 +58,25 @@ def shard_configs(supernet, configs, rank, world):
     return shard_indices(len(configs), rank, world, weights=[_cost(supernet, c) for c in configs])
 
 
-def gather_results(local, world=None):
+def gather_results(local, world=None, device=None):
     """{config_key: result} of this rank -> the union over all ranks (one all_gather_object; identity without a
-    process group)."""
+    process group).  `device`: this rank's GPU -- under backend "nccl" (RCCL) the object gather serialises through
+    torch.cuda.current_device(), which must be the rank's own card."""
     dist = torch.distributed
     if not (dist.is_available() and dist.is_initialized()):
         return dict(local)
     world = dist.get_world_size() if world is None else world
     if world <= 1:
         return dict(local)
+    if world != dist.get_world_size():
+        raise _lib.SugarError("gather_results(world=%d) under a process group of %d ranks" % (world, dist.get_world_size()))
     parts = [None] * world
-    dist.all_gather_object(parts, local)
+    dev = torch.device(device) if device is not None else None
+    if dev is not None and dev.type == "cuda":
+        with torch.cuda.device(dev):
+            dist.all_gather_object(parts, local)
+    else:
+        dist.all_gather_object(parts, local)
     out = {}
     for p in parts:
         out.update(p)
@@ -143,6 +153,7 @@ def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transfor
             if recal_loader is not None:
                 batch_forward(recal_loader, model, device=str(dev))
             with torch.no_grad():
+                # un-sharded on purpose: this rank's subnet over the whole list (a live process group does not shard)
                 vectors = extract_vectors(model, packed, norm=norm)
                 eer, dcf = veri_validate(veri_loader, model, norm=norm, p_target=p_target, device=str(dev),
                                          vectors=vectors)
@@ -155,4 +166,4 @@ def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transfor
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
-    return gather_results(results, world) if gather else results
+    return gather_results(results, world, dev) if gather else results

@@ -104,14 +104,27 @@ class PackedUtterances:
         return len(self.files)
 
 
-def _dist_info(rank, world_size):
-    """(rank, world) of this call: the explicit arguments, else the initialised process group, else (0, 1)."""
-    if world_size is not None:
-        return (0 if rank is None else int(rank)), int(world_size)
+def _dist_info(rank, world_size, shard):
+    """
+    (rank, world) of this call.  Sharding is OPT-IN: an explicit ``world_size`` (with ``rank``, default: the process
+    group's), or ``shard=True`` (both from the initialised process group).  A process group that merely exists does NOT
+    shard: under the reference's multi-GPU evaluation every rank holds its OWN checkpoint / subnet and embeds the whole
+    list with no collective (scripts/train_vox2_veri.py:385-403 strides CHECKPOINTS over the GPUs, not utterances).
+    """
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+    live = dist.is_available() and dist.is_initialized()
+    if world_size is None and not shard:
+        return 0, 1
+    if world_size is None:
+        if not live:
+            return 0, 1
+        world_size = dist.get_world_size()
+    if rank is None:
+        rank = dist.get_rank() if live else 0
+    rank, world_size = int(rank), int(world_size)
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("extract_vectors: rank %d outside world_size %d" % (rank, world_size))
+    return rank, world_size
 
 
 class _Subset:
@@ -128,21 +141,24 @@ class _Subset:
 
 
 def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_size=1, max_frames=262144,
-                    rank=None, world_size=None):
+                    rank=None, world_size=None, shard=False):
     """
     model   : WrappedModel / SpeakerModel from sugar_amd.models
     datalst : an indexable dataset of {"file": str, "input": Tensor[n_seg, L] or [L]} (sugar/database.py:136-142),
               or a PackedUtterances built from one (then `device`, `batch_size`, `max_frames` are the packing's)
     n_jobs  : kept for signature parity (the reference's joblib threads / DataLoader workers); unused
-    rank, world_size : multi-GPU extraction (BASELINE config 4).  Default: the initialised torch.distributed process
-              group if there is one, else a single rank.  With more than one rank every rank embeds a shard of the
-              list (the reference's "GPU g takes items g, g+N, ..." striding, scripts/train_vox2_veri.py:385-403;
-              longest-first round-robin when the dataset exposes `lengths`), the shards are exchanged with ONE
-              all-gather of the [n_local, 192] blocks (RCCL over xGMI; gloo in tests) and EVERY rank returns the
-              complete table, rows and files in the order of `datalst` -- bit-identical to the one-rank result.
+    rank, world_size, shard : multi-GPU extraction of ONE model's vectors (BASELINE config 4) -- opt-in, never
+              inferred from a process group that happens to exist: pass ``world_size`` (and ``rank``), or
+              ``shard=True`` to take both from the initialised torch.distributed group.  ALL ranks must then call with
+              the SAME model and list: every rank embeds a shard (items rank, rank + N, ...; longest-first round-robin
+              when the dataset exposes `lengths`), the shards are exchanged with one all-gather of the [n_local, 192]
+              blocks (RCCL over xGMI; gloo in tests) and EVERY rank returns the complete table, rows and files in the
+              order of `datalst` -- bit-identical to the one-rank result.  The default (no sharding, no collective) is
+              the reference's behaviour under a live group: each rank evaluates its own checkpoint over the whole list
+              (scripts/train_vox2_veri.py:385-403), which is also what `evaluate_subnets` and `veri_validate` do.
     Returns a VectorTable: {file: Tensor[n_seg, 192]} on the device.
     """
-    rank, world = _dist_info(rank, world_size)
+    rank, world = _dist_info(rank, world_size, shard)
     if world > 1:
         return _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank, world)
     packed = datalst if isinstance(datalst, PackedUtterances) else None
@@ -187,14 +203,15 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
 
 
 def _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank, world):
-    """extract_vectors on `world` ranks: shard -> embed -> one all-gather -> the complete table on every rank."""
+    """extract_vectors on `world` ranks: shard -> embed -> exchange -> the complete table on every rank."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != world:
         raise _lib.SugarError("extract_vectors(world_size=%d) needs an initialised torch.distributed process group of "
                               "that size (backend 'nccl' = RCCL on the GPUs)" % world)
     if isinstance(datalst, PackedUtterances):
         # the list is already on this rank's GPU in length-sorted batches: deal the batches round-robin (neighbouring
-        # batches have neighbouring lengths, so the shards balance); every rank knows every rank's rows
+        # batches have neighbouring lengths, so the shards balance); every rank knows every rank's rows, so the
+        # exchange is ONE all_gather_into_tensor and nothing else
         packed, device = datalst, datalst.device
         model.to(device)
         model.eval()
@@ -204,29 +221,42 @@ def _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank,
         lanes = stream_lanes(device)
         for lane in lanes:
             lane.wait_stream(main)
-        mine = [k for k in range(len(packed.batches)) if k % world == rank]
+        share = [[k for k in range(len(packed.batches)) if k % world == r] for r in range(world)]
         parts = []
-        for j, k in enumerate(mine):
+        for j, k in enumerate(share[rank]):
             idx, flat, plan = packed.batches[k]
             with torch.cuda.stream(lanes[j % len(lanes)]):
                 parts.append(spk._embed_flat(sub, flat, plan, bool(norm)))
         for lane in lanes:
             main.wait_stream(lane)
         local = torch.cat(parts) if parts else torch.empty(0, 192, dtype=torch.float32, device=device)
-        blocks = gather_vectors(local, world)
+        sizes = [sum(int(packed.batches[k][0].numel()) for k in ks) for ks in share]
+        blocks = gather_vectors(local, world, sizes=sizes)
         out = torch.empty(packed.n_rows, 192, dtype=torch.float32, device=device)
         for r in range(world):
-            rows = [packed.batches[k][0] for k in range(len(packed.batches)) if k % world == r]
-            if rows:
-                out[torch.cat(rows)] = blocks[r].to(device)
+            if share[r]:
+                out[torch.cat([packed.batches[k][0] for k in share[r]])] = blocks[r]
         return VectorTable(packed.files, packed.counts, out)
     n = len(datalst)
     mine = shard_indices(n, rank, world, getattr(datalst, "lengths", None))
-    local = extract_vectors(model, _Subset(datalst, mine), norm, device, 0, batch_size, max_frames, rank=0, world_size=1)
+    local = extract_vectors(model, _Subset(datalst, mine), norm, device, 0, batch_size, max_frames)
+    # two collectives: one object gather of the host-side bookkeeping (item indices, names, segment counts -- which
+    # also gives every rank's row count), one all_gather_into_tensor of the vectors
     meta = [None] * world
-    dist.all_gather_object(meta, (mine, local.files, local.counts))      # host-side bookkeeping: names + segment counts
-    blocks = gather_vectors(local.matrix, world)
+    with _collective_device(local.matrix):
+        dist.all_gather_object(meta, (mine, local.files, local.counts))
+    blocks = gather_vectors(local.matrix, world, sizes=[sum(m[2]) for m in meta])
     return VectorTable(*assemble_shards(n, meta, blocks, local.matrix.device))
+
+
+def _collective_device(t):
+    """
+    Context for a torch.distributed call next to tensor `t`: under backend "nccl" (RCCL) object collectives serialise
+    through `torch.cuda.current_device()` and tensor collectives pick their communicator by it, so the current device
+    must be the rank's own GPU -- which a caller that only passed device="cuda:N" has not set.
+    """
+    import contextlib
+    return torch.cuda.device(t.device) if t.is_cuda else contextlib.nullcontext()
 
 
 def assemble_shards(n, meta, blocks, device):
@@ -252,27 +282,32 @@ def assemble_shards(n, meta, blocks, device):
     return files, counts, matrix
 
 
-def gather_vectors(local, world_size=None):
+def gather_vectors(local, world_size=None, sizes=None):
     """
-    Multi-GPU exchange step: every rank embedded a shard of the utterances; one all-gather of the
-    [n_local, 192] float32 blocks (RCCL over xGMI on GPUs, gloo in CPU tests) gives every rank all vectors.
+    Multi-GPU exchange step: every rank embedded a shard of the utterances; ONE all_gather_into_tensor of
+    the [n_local, 192] float32 blocks (RCCL over xGMI on GPUs, gloo in CPU tests) gives every rank all vectors.
     ``local``: Tensor [n_local, D]; shards may differ in size (padded to the max for the collective).
+    ``sizes``: every rank's row count when the caller knows them (extract_vectors does); else they are exchanged first
+    with one all_gather_object.
     Returns the list of per-rank tensors in rank order (on ``local``'s device).
     """
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [local]
     world = dist.get_world_size() if world_size is None else world_size
-    # a gloo group moves host memory: stage device tensors through the host (tests; two ranks sharing one GPU)
-    wire = local.cpu() if (local.is_cuda and dist.get_backend() == "gloo") else local
-    n = torch.tensor([wire.shape[0]], dtype=torch.int64, device=wire.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    m = max(sizes)
-    pad = wire if wire.shape[0] == m else torch.cat([wire, wire.new_zeros(m - wire.shape[0], wire.shape[1])])
-    buf = wire.new_empty(world * m, wire.shape[1])
-    dist.all_gather_into_tensor(buf, pad.contiguous())
+    with _collective_device(local):
+        if sizes is None:
+            sizes = [None] * world
+            dist.all_gather_object(sizes, int(local.shape[0]))
+        sizes = [int(x) for x in sizes]
+        if len(sizes) != world or sizes[dist.get_rank()] != local.shape[0]:
+            raise _lib.SugarError("gather_vectors: sizes %r do not match this rank's %d rows" % (sizes, local.shape[0]))
+        # a gloo group moves host memory: stage device tensors through the host (tests; two ranks sharing one GPU)
+        wire = local.cpu() if (local.is_cuda and dist.get_backend() == "gloo") else local
+        m = max(sizes)
+        pad = wire if wire.shape[0] == m else torch.cat([wire, wire.new_zeros(m - wire.shape[0], wire.shape[1])])
+        buf = wire.new_empty(world * m, wire.shape[1])
+        dist.all_gather_into_tensor(buf, pad.contiguous())
     return [buf[r * m:r * m + sizes[r]].to(local.device) for r in range(world)]
 
 

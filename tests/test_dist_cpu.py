@@ -27,6 +27,16 @@ def _worker(rank, world, port, n_utts, q):
     table = synth.normal("dist/emb", (n_utts, 192), seed=5)
     local = table[mine]
     parts = gather_vectors(local)
+    # the same exchange when the caller knows every rank's row count: one collective, same blocks
+    known = [len(shard_indices(n_utts, r, world, lengths)) for r in range(world)]
+    parts2 = gather_vectors(local, world, sizes=known)
+    assert all(torch.equal(a, b) for a, b in zip(parts, parts2))
+    # sharding is opt-in: a live process group alone does not shard (evaluate_subnets / veri_validate rely on it)
+    from sugar_amd.vectors import _dist_info
+    assert _dist_info(None, None, False) == (0, 1)
+    assert _dist_info(None, None, True) == (rank, world)
+    assert _dist_info(None, world, False) == (rank, world)
+    assert _dist_info(1, 4, False) == (1, 4)
     full = torch.empty(n_utts, 192)
     for r, part in enumerate(parts):
         full[shard_indices(n_utts, r, world, lengths)] = part
@@ -125,3 +135,13 @@ def test_sweep_shards_and_gathers_world2():
     assert full0 == full1 and len(full0) == len({k for k, _ in full0})
     for _, v in full0:
         assert int(v["eer"]) in (mine0 if v["rank"] == 0 else mine1)
+
+
+def test_sharding_is_opt_in_without_a_group():
+    from sugar_amd.vectors import _dist_info
+    assert _dist_info(None, None, False) == (0, 1)
+    assert _dist_info(None, None, True) == (0, 1)          # shard=True without a process group: one rank
+    assert _dist_info(None, 1, False) == (0, 1)
+    import pytest
+    with pytest.raises(ValueError):
+        _dist_info(3, 2, False)

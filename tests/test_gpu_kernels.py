@@ -393,8 +393,35 @@ def test_cosine_trials_full_size_config4_against_reference():
 def test_cosine_tiny_norm_uses_eps_per_vector():
     a = torch.tensor([[3e-9, 4e-9] + [0.0] * 190])
     b = torch.tensor([[1.0, 2.0, 2.0] + [0.0] * 189])
-    got = sugar_amd.calculate_score(a.to(DEV), b.to(DEV))
+    got = sugar_amd.calculate_score(a.to(DEV), b.to(DEV), "cosine")
     assert abs(got - ref_cpu.cosine_score(a, b)) < 1e-6
+
+
+def test_norm2_and_list_of_modes_match_reference():
+    """calculate_score(mode="norm2") -- the reference's default -- and list-of-modes score_trials
+    (sugar/scores.py:141-145, 151-152, 175-177) against the reference's own outputs (tests/golden/norm2.npz,
+    oracle/make_golden_norm2.py): 40 utterances of 1-3 segment vectors, 300 trials.  Float bar: 2e-6 absolute on scores
+    of magnitude 1-3 (f32 arithmetic on both sides, different summation order)."""
+    import os
+    from oracle.make_golden_norm2_inputs import inputs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = np.load(os.path.join(root, "tests", "golden", "norm2.npz"))
+    vecs, lab, a, b = inputs()
+    vectors = {"utt%03d" % i: v.to(DEV) for i, v in enumerate(vecs)}
+    trials = [{"label": int(l), "enroll": "utt%03d" % i, "test": "utt%03d" % j} for l, i, j in zip(lab, a, b)]
+    scores, labels, pairs = sugar_amd.score_trials(trials, vectors, mode="norm2", n_jobs=1)
+    assert scores.shape == (300,) and np.abs(scores - gold["norm2"]).max() < 2e-6
+    both, labels2, _ = sugar_amd.score_trials(trials, vectors, mode=["cosine", "norm2"], n_jobs=1)
+    assert both.shape == (300, 2) and np.abs(both - gold["cosine_norm2"]).max() < 2e-6
+    assert np.array_equal(labels, gold["labels"]) and np.array_equal(labels2, gold["labels"])
+    assert np.array_equal(np.argsort(scores, kind="stable"), np.argsort(gold["norm2"], kind="stable"))
+    # the default mode of calculate_score is norm2, as in the reference; a list gives a list
+    assert abs(sugar_amd.calculate_score(vectors["utt001"], vectors["utt002"]) - float(gold["default_1_2"])) < 2e-6
+    pair = sugar_amd.calculate_score(vectors["utt001"], vectors["utt002"], ["cosine", "norm2"])
+    assert isinstance(pair, list) and abs(pair[1] - float(gold["default_1_2"])) < 2e-6
+    assert abs(pair[0] - ref_cpu.cosine_score(vecs[1], vecs[2])) < 2e-6
+    with pytest.raises(ValueError):
+        sugar_amd.score_trials(trials, vectors, mode="plda")
 
 
 def test_l2norm_matches_f_normalize():

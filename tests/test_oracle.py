@@ -110,3 +110,17 @@ def test_mac_known_answers():
     # SURVEY 8d / BASELINE.md section 2: conv + linear MACs per utterance
     assert abs(ref_cpu.count_macs(layout.BASE, 301) / 1.4423e9 - 1) < 1e-3
     assert abs(ref_cpu.count_macs(layout.LARGEST, 301) / 1.9319e9 - 1) < 1e-3
+
+
+def test_oracle_norm2_scoring_matches_reference_outputs():
+    """oracle norm2_score / list-of-modes scoring against the reference's own calculate_score / score_trials outputs
+    (tests/golden/norm2.npz, generated by oracle/make_golden_norm2.py from sugar/scores.py:114-216)."""
+    import os
+    import numpy as np
+    from oracle import ref_cpu
+    from oracle.make_golden_norm2_inputs import inputs
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "norm2.npz"))
+    vecs, lab, a, b = inputs()
+    assert np.abs(ref_cpu.score_trials(a, b, vecs, mode="norm2") - gold["norm2"]).max() < 1e-6
+    assert np.abs(ref_cpu.score_trials(a, b, vecs, mode=["cosine", "norm2"]) - gold["cosine_norm2"]).max() < 1e-6
+    assert abs(ref_cpu.norm2_score(vecs[1], vecs[2]) - float(gold["default_1_2"])) < 1e-6

@@ -59,3 +59,38 @@ def test_noalloc_fbank_rejects_oversize_and_takes_the_limit():
     lens = [40800 + 159] * 64
     assert BatchPlan(lens, DEV).R == 16384
     assert torch.equal(_run(lens, 13, torch.float32, True), _run(lens, 13, torch.float32, False))
+
+
+def test_noalloc_fbank_runs_under_stream_capture_and_allocates_nothing():
+    """The entry point's defining property: after its one-off set-up it allocates nothing and never synchronises, so it
+    can be captured into a HIP graph (a hipMalloc or a sync inside a capturing stream fails the capture) and the device's
+    free memory does not move over repeated calls."""
+    lens = [48000] * 4 + [20000, 7777]
+    wavs = synth.ragged_waveforms(lens, seed=21)
+    flat = torch.cat(wavs).to(DEV)
+    plan = BatchPlan(lens, DEV)
+    want = _run(lens, 21, torch.bfloat16, noalloc=False)
+    feats = torch.zeros((plan.R, 80), dtype=torch.bfloat16, device=DEV)
+    lib = _lib.lib()
+
+    def call(stream):
+        _lib.check(lib.sugar_fbank_fwd_noalloc(flat.data_ptr(), plan.wav_off.data_ptr(), plan.wav_len.data_ptr(),
+                                               plan.row_off.data_ptr(), plan.B, plan.R, plan.t_max, feats.data_ptr(),
+                                               _lib.SUGAR_BF16, stream), "fbank_noalloc")
+
+    call(torch.cuda.current_stream().cuda_stream)             # warm call: per-device set-up (hipGetSymbolAddress) done
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(8):
+        call(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0               # hipMemGetInfo: no device allocation in 8 calls
+    feats.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert not feats.any()                                     # captured, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(feats.cpu(), want)
