@@ -104,6 +104,103 @@ class PackedUtterances:
         return len(self.files)
 
 
+class _HostFeed:
+    """
+    Host-fed batches for extract_vectors' list path (the reference feeds its forward from DataLoader workers,
+    sugar/vectors.py:126-153): a producer thread packs batch k + 1 into a PINNED staging buffer (`workers` threads copy
+    the segments side by side: torch's CPU copy releases the GIL) and sends it over PCIe on a copy stream while the GPU
+    computes batch k.  Three slots (pinned buffer + device buffer + two events each), so packing, the PCIe copy and the
+    compute of three consecutive batches overlap; a slot is reused once the forward that read it has finished.
+    Without this the list path issued one synchronous pageable-memory copy per segment (4 874 of them for BASELINE
+    config 4) from the thread that also launches the kernels.
+    """
+    SLOTS = 3
+
+    def __init__(self, device, segs, lengths, batches, workers):
+        import ctypes
+        import queue
+        import threading
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+        from .transforms import BatchPlan
+        self.device = device
+        cap = max(sum(lengths[i] for i in b) for b in batches)
+        self.pinned = [torch.empty(cap, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)]
+        self.dev = [torch.empty(cap, dtype=torch.float32, device=device) for _ in range(self.SLOTS)]
+        self.h2d_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.free = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.copy_stream = torch.cuda.Stream(device)
+        self.q = queue.Queue()
+        self.sem = threading.Semaphore(self.SLOTS)                # slots the consumer has handed back (see done())
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+        self._stop = False
+        self.stats = {"pack_s": 0.0, "wait_slot_s": 0.0, "bytes": 0}   # host-side seconds of the producer (diagnostics)
+
+        def pack(dst, pieces):
+            # float32 segments move with a plain memmove through ctypes, which drops the GIL for the call: the worker
+            # threads then really copy side by side (tensor.copy_ from 8 threads measured 13 GB/s, one thread 10.8)
+            base = dst.data_ptr()
+            for off, seg in pieces:
+                if seg.dtype == torch.float32 and seg.is_contiguous():
+                    ctypes.memmove(base + 4 * off, seg.data_ptr(), 4 * seg.numel())
+                else:
+                    dst[off:off + seg.numel()].copy_(seg.reshape(-1))
+
+        def produce():
+            try:
+                with torch.cuda.device(device):
+                    for k, batch in enumerate(batches):
+                        t0 = time.perf_counter()
+                        self.sem.acquire()                        # slot k % SLOTS: handed back by done() ...
+                        if self._stop:
+                            return
+                        s = k % self.SLOTS
+                        if k >= self.SLOTS:
+                            self.free[s].synchronize()            # ... and the forward that read it has finished
+                        t1 = time.perf_counter()
+                        pieces, off = [], 0
+                        for i in batch:
+                            pieces.append((off, segs[i]))
+                            off += lengths[i]
+                        n = max(1, min(len(pieces), self.pool._max_workers))
+                        list(self.pool.map(lambda part: pack(self.pinned[s], part), [pieces[j::n] for j in range(n)]))
+                        self.stats["wait_slot_s"] += t1 - t0
+                        self.stats["pack_s"] += time.perf_counter() - t1
+                        self.stats["bytes"] += 4 * off
+                        plan = BatchPlan([lengths[i] for i in batch], device)
+                        idx = torch.tensor(batch, dtype=torch.int64).to(device)
+                        with torch.cuda.stream(self.copy_stream):
+                            self.dev[s][:off].copy_(self.pinned[s][:off], non_blocking=True)
+                            self.h2d_done[s].record(self.copy_stream)
+                        self.q.put((k, s, off, plan, idx))
+                self.q.put(None)
+            except BaseException as e:                            # surfaces in the consumer
+                self.q.put(e)
+
+        self.thread = threading.Thread(target=produce, name="sugar-hostfeed", daemon=True)
+        self.thread.start()
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def done(self, slot, stream):
+        """The forward reading `slot` has been enqueued on `stream`: the slot may be refilled once it has run."""
+        self.free[slot].record(stream)
+        self.sem.release()
+
+    def close(self):
+        self._stop = True
+        self.sem.release()                                        # a producer waiting for a slot sees _stop
+        self.thread.join()
+        self.pool.shutdown(wait=True)
+
+
 def _dist_info(rank, world_size, shard):
     """
     (rank, world) of this call.  Sharding is OPT-IN: an explicit ``world_size`` (with ``rank``, default: the process
@@ -146,7 +243,8 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
     model   : WrappedModel / SpeakerModel from sugar_amd.models
     datalst : an indexable dataset of {"file": str, "input": Tensor[n_seg, L] or [L]} (sugar/database.py:136-142),
               or a PackedUtterances built from one (then `device`, `batch_size`, `max_frames` are the packing's)
-    n_jobs  : kept for signature parity (the reference's joblib threads / DataLoader workers); unused
+    n_jobs  : host threads that pack the next batch into pinned staging memory while the GPU computes (the reference's
+              joblib threads / DataLoader workers, sugar/vectors.py:117-121, 130-133); only used for host-resident lists
     rank, world_size, shard : multi-GPU extraction of ONE model's vectors (BASELINE config 4) -- opt-in, never
               inferred from a process group that happens to exist: pass ``world_size`` (and ``rank``), or
               ``shard=True`` to take both from the initialised torch.distributed group.  ALL ranks must then call with
@@ -192,11 +290,39 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
             segs.extend(ss)
         lengths = [int(s.numel()) for s in segs]
         out = torch.empty(len(segs), 192, dtype=torch.float32, device=device)
-        for k, batch in enumerate(plan_batches(lengths, max(1, batch_size), max_frames)):
-            with torch.cuda.stream(lanes[k % len(lanes)]):
-                wavs = [segs[i].to(device, non_blocking=True) for i in batch]
-                emb = spk.embed_ragged(wavs, normalize=bool(norm))
-                out[torch.tensor(batch, device=device)] = emb
+        batches = plan_batches(lengths, max(1, batch_size), max_frames)
+        if segs and not any(s.is_cuda for s in segs):
+            # host-resident list: pinned, triple-buffered staging on a copy stream, packed by n_jobs host threads
+            from .transforms import LogMelFbanks
+            if not isinstance(getattr(spk, "__T__", None), LogMelFbanks):
+                raise _lib.SugarError("extract_vectors needs the fused LogMelFbanks + TDNN path")
+            sub = spk._subnet()
+            sub.eval_handle(device)                               # pack the weights before the pipeline starts
+            feed = _HostFeed(device, segs, lengths, batches, max(1, int(n_jobs)))
+            # the batch plans and row indices are allocated by the producer thread (on ITS stream) and read by kernels
+            # on the lanes: they stay referenced until the lanes have been joined, or the caching allocator would hand
+            # their memory to the producer's next batch while a lane still has to read it
+            keep = []
+            try:
+                for k, slot, total, plan, idx in feed:
+                    keep.append((plan, idx))
+                    lane = lanes[k % len(lanes)]
+                    lane.wait_event(feed.h2d_done[slot])
+                    with torch.cuda.stream(lane):
+                        out[idx] = spk._embed_flat(sub, feed.dev[slot][:total], plan, bool(norm))
+                    feed.done(slot, lane)
+            finally:
+                feed.close()
+            extract_vectors.last_hostfeed_stats = dict(feed.stats)   # diagnostics (tools/hostfed_bench.py)
+            for lane in lanes:
+                lane.synchronize()
+            del keep
+        else:
+            for k, batch in enumerate(batches):
+                with torch.cuda.stream(lanes[k % len(lanes)]):
+                    wavs = [segs[i].to(device, non_blocking=True) for i in batch]
+                    emb = spk.embed_ragged(wavs, normalize=bool(norm))
+                    out[torch.tensor(batch, device=device)] = emb
     for lane in lanes:
         main.wait_stream(lane)
     return VectorTable(files, counts, out)

@@ -333,3 +333,25 @@ def test_sampled_subnets_match_oracle(precision, supernet, sup_state):
         worst_c, worst_r = min(worst_c, c), max(worst_r, r)
         assert c >= TOL[precision] and r < REL[precision], (k, cfg, c, r)
     print("sampled subnets", precision, "worst cosine %.6f  worst rel L2 %.2e" % (worst_c, worst_r))
+
+
+def test_host_fed_list_equals_resident_list(supernet):
+    """extract_vectors over a HOST-resident list (pinned triple-buffered staging on a copy stream, packed by n_jobs
+    threads) gives bit-identical vectors to the same list on the GPU and to PackedUtterances, over more batches than
+    staging slots (slot reuse), for 1 and 3 packing threads, float32 and float64 inputs."""
+    model = _model(supernet, layout.SMALLEST, "bf16")
+    n_utts = 37
+    lens = synth.ragged_lengths(n_utts, lo=20000, hi=70000, seed=21).tolist()
+    wavs = synth.ragged_waveforms(lens, seed=21)
+    segs = [1 + (i % 3 == 1) for i in range(n_utts)]
+    host = _Utts(wavs, segs)
+    resident = _Utts([w.to(DEV) for w in wavs], segs)
+    want = sugar_amd.extract_vectors(model, resident, norm=True, device=DEV, batch_size=4)
+    for jobs in (1, 3):
+        got = sugar_amd.extract_vectors(model, host, norm=True, device=DEV, batch_size=4, n_jobs=jobs)
+        assert list(got.keys()) == list(want.keys())
+        assert torch.equal(got.matrix, want.matrix), jobs
+    packed = sugar_amd.extract_vectors(model, sugar_amd.PackedUtterances(host, DEV, batch_size=4), norm=True)
+    assert torch.equal(packed.matrix, want.matrix)
+    host64 = _Utts([w.double() for w in wavs], segs)
+    assert torch.equal(sugar_amd.extract_vectors(model, host64, norm=True, device=DEV, batch_size=4).matrix, want.matrix)
