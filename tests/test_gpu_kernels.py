@@ -325,6 +325,61 @@ def test_stage_taps_match_reference_bf16(name, golden, meta, supernet):
         assert v < 1.5e-2, (k, errs)
 
 
+# Full-width networks at T = 301, stage by stage, against the REFERENCE's module outputs (tests/golden/round3.npz,
+# oracle/make_golden_round3.py; every tap stored at the 24 frames of oracle/round3_inputs.py::FRAMES, all channels).
+# This is the oracle check of the kernels only full-width subnets reach: res2_chain_kernel on 64-channel groups of 3
+# taps, res2_wide_kernel on 128-channel groups of 5 taps, the weights-in-registers 512 x 512 GEMM, the 1024-channel
+# GEMMs, the 256 x 256 catconv.  f32: same 1e-4 bar as the narrow subnets; bf16: relative L2 over the stored rows
+# < 1.5e-2 (same bar and reasoning as test_stage_taps_match_reference_bf16; measured values are printed).
+# "bf16-wreg": the same with gemm_wreg_min_r = 0, i.e. every K = 512 conv, layer1 and pooling.linear1 on the
+# weights-in-registers GEMM that large batches use (one utterance alone stays below its threshold).
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16-wreg"])
+@pytest.mark.parametrize("net", ["base", "wide_full"])
+def test_stage_taps_full_width_T301_match_reference(net, precision):
+    if precision == "bf16-wreg":
+        with _lib.tuned(gemm_wreg_min_r=0):
+            return _stage_taps_T301(net, "bf16")
+    return _stage_taps_T301(net, precision)
+
+
+def _stage_taps_T301(net, precision):
+    import os
+    from oracle.round3_inputs import FRAMES, NETS
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round3.npz"))
+    family, shape_args, cfg = NETS[net]
+    sup = getattr(sugar_amd, family)()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(*shape_args), seed=0))
+    sub = sup.clone(cfg).set_precision(precision)
+    x = ref_cpu.logmel_fbank(synth.waveforms(1, 48000, seed=5)).squeeze(1)      # oracle features -> backbone only
+    T = x.shape[2]
+    assert T == 301
+    feats = x[0].t().contiguous().to(torch.bfloat16 if precision == "bf16" else torch.float32).to(DEV)
+    row_off = torch.tensor([0, T], dtype=torch.int32, device=DEV)
+    dims = sub.packed_dims()
+    depth, ch, _, ccat = cfg
+    taps = [(0, "layer1", None)]
+    for i in range(depth):
+        taps += [(1 + 4 * i, "b%d.first" % i, i), (2 + 4 * i, "b%d.res2" % i, i), (3 + 4 * i, "b%d.last" % i, i),
+                 (4 + 4 * i, "b%d.out" % i, i)]
+    taps += [(100, "catconv", None)]
+    errs = {}
+    rel = lambda got, want: ((got.double() - want.double()).norm() / want.double().norm()).item()
+    for what, key, i in taps:
+        act, _ = sub.tap(feats, row_off, 1, T, T, what)
+        act = _unpack(act.float().cpu(), key.split(".")[-1], dims, i)[FRAMES]
+        want = torch.from_numpy(gold["stage301/%s/%s" % (net, key)]).t()          # [24 frames, C]
+        errs[key] = rel(act[:, :want.shape[1]], want)
+    pooled, emb = sub.tap(feats, row_off, 1, T, T, 101)
+    pooled, cp = pooled.cpu()[0], dims["ccatp"]
+    errs["pool"] = rel(torch.cat([pooled[:ccat], pooled[cp:cp + ccat]]), torch.from_numpy(gold["stage301/%s/pool" % net]))
+    errs["embed"] = rel(emb.cpu()[0], torch.from_numpy(gold["stage301/%s/embed" % net]))
+    print(net, precision, "rel L2 per stage at T = 301:", {k: "%.2e" % v for k, v in errs.items()})
+    bar = 1e-4 if precision == "fp32" else 1.5e-2
+    for k, v in errs.items():
+        assert v < bar, (k, errs)
+    sub.release()
+
+
 # ------------------------------------------------------------------------------------------ scoring / l2norm
 def test_cosine_trials_match_calculate_score(golden, meta):
     segs = meta["score_segs"]
