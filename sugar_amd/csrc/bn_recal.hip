@@ -21,7 +21,11 @@ namespace sugar {
 namespace {
 
 constexpr float BN_EPS = 1e-5f;
-constexpr int BN_BLOCKS = 128;      // row blocks of the partial sums
+constexpr int BN_BLOCKS = 128;      // row blocks of the partial sums, wide tensors
+// Narrow tensors (the 64 .. 128-channel Res2 steps: one or two channel slabs) get four times the row blocks: with 128
+// the launch was 128 workgroups walking 19 rows per thread in dependent round trips (10 us for 10 MB); the partial table
+// of a launch stays within bn_workspace_doubles
+constexpr int BN_BLOCKS_NARROW = 512, BN_NARROW_C = 128;
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, int ld, int64_t R, int C,
@@ -72,18 +76,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ z, 
 // 256 threads = 32 channels x 8 partial lanes: every lane adds its partials (k = lane, lane + 8, ...: independent
 // loads), the 8 lane sums of a channel are added in lane order, so the result does not depend on scheduling.  (One
 // thread per channel walking all 128 partials was a 36 us chain of dependent loads, 28 times per step.)
+// LP = partial lanes per channel: 8 (wide tensors, 32 channels per workgroup) or 32 (narrow ones with 512 row blocks: 8
+// channels per workgroup, 16 partials per lane).
+template <int LP>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblk, int C, double n,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, float momentum,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[2][8][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  constexpr int CW = 256 / LP;        // channels per workgroup
+  __shared__ double red[2][LP][CW];
+  const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+  const int c = blockIdx.x * CW + tx;
   double a = 0.0, b = 0.0;
   if (c < C) {
-#pragma unroll 4
-    for (int k = ty; k < nblk; k += 8) {
+#pragma unroll 8
+    for (int k = ty; k < nblk; k += LP) {
       a += part[((size_t)k * 2 + 0) * C + c];
       b += part[((size_t)k * 2 + 1) * C + c];
     }
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   a = 0.0;
   b = 0.0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < LP; ++k) {
     a += red[0][k][tx];
     b += red[1][k][tx];
   }
@@ -212,22 +220,31 @@ void bn_state_free(BNState* st) {
   *st = BNState();
 }
 
-int bn_workspace_doubles(int c_max) { return BN_BLOCKS * 2 * c_max; }
+int bn_workspace_doubles(int c_max) {
+  const int narrow = BN_BLOCKS_NARROW * 2 * BN_NARROW_C, wide = BN_BLOCKS * 2 * c_max;
+  return wide > narrow ? wide : narrow;
+}
 
 int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, float momentum, double* d_part,
                     float* d_scale, float* d_shift, int dtype, hipStream_t s) {
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(C % E == 0 && C <= st.n && ld % E == 0 && ((uintptr_t)d_z & 15) == 0 && R > 0,
                   "bn_batch: bad shape C %d ld %d", C, ld);
-  const int nblk = (int)(R < 32 * BN_BLOCKS ? ceil_div(R, 32) : BN_BLOCKS);
+  const bool narrow = C <= BN_NARROW_C;
+  const int cap = narrow ? BN_BLOCKS_NARROW : BN_BLOCKS;
+  const int nblk = (int)(R < 32 * (int64_t)cap ? ceil_div(R, 32) : cap);
   const dim3 grid((unsigned)ceil_div(C / E, 8), (unsigned)nblk);
   if (dtype == SUGAR_F32)
     hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)d_z, ld, R, C, d_part);
   else
     hipLaunchKernelGGL(bn_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_z, ld, R, C, d_part);
   SUGAR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, s, d_part, nblk, C, (double)R,
-                     st.gamma(), st.beta(), st.mean(), st.var(), momentum, d_scale, d_shift);
+  if (narrow)
+    hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((unsigned)ceil_div(C, 8)), dim3(256), 0, s, d_part, nblk, C, (double)R,
+                       st.gamma(), st.beta(), st.mean(), st.var(), momentum, d_scale, d_shift);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, s, d_part, nblk, C, (double)R,
+                       st.gamma(), st.beta(), st.mean(), st.var(), momentum, d_scale, d_shift);
   SUGAR_LAUNCH_CHECK();
   const int64_t items = R * (C / E);
   const unsigned blocks = (unsigned)(ceil_div(items, 256) < 4096 ? ceil_div(items, 256) : 4096);

@@ -504,10 +504,19 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
   };
   if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc;
 
-  ConvIO io;
-  io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
-  if ((rc = launch_conv(raw_conv(n->layer1), io, w.rowseg, R, dt, s)) || (rc = bn(w.S, n->c0p, n->c0p, n->bn_layer1)))
-    return rc;
+  {
+    const ConvLayer l1 = raw_conv(n->layer1);
+    if (layer1_as_tap_gemm(n)) {                      // the eval path's tap GEMM with the affine switched off
+      if ((rc = launch_pad_rows(l1, feats, w.featp, row_off, B, R, t_max, s)) ||
+          (rc = launch_gemm_taps(l1, w.featp, w.orow, w.S, n->c0p, row_off, B, R, t_max, s, false)))
+        return rc;
+    } else {
+      ConvIO io;
+      io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
+      if ((rc = launch_conv(l1, io, w.rowseg, R, dt, s))) return rc;
+    }
+    if ((rc = bn(w.S, n->c0p, n->c0p, n->bn_layer1))) return rc;
+  }
 
   const int ldcat = n->depth * n->c0p;
   for (int i = 0; i < n->depth; ++i) {
