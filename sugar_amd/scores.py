@@ -246,3 +246,79 @@ def snorm(scores, cohort, nTop=None, std_eps=1e-8, device="cuda:0"):
     n_trials = len(_trial_columns(scores)[0])
     keys, mat = _cohort_matrix(cohort, torch.device(device))
     return _snorm_gpu(scores, cohort, mat.shape[1], n_trials, std_eps, device)
+
+
+def score_batch(vec, batch, mode="cosine", device="cuda:0"):
+    """
+    sugar/scores.py:56-74: cosine similarity of every row of `vec` [n, D] with every row of `batch` [m, D] -> float32
+    ndarray [n, m] (F.cosine_similarity broadcast, eps 1e-8).  One sugar_cohort_scores launch with every row of `vec` as
+    an utterance of its own.
+    """
+    if mode != "cosine":
+        raise ValueError("only mode='cosine' is supported (as in the reference)")
+    dev = vec.device if vec.is_cuda else torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.SugarError("sugar_amd runs on an MI355X only: pass device='cuda:N' (there is no CPU fallback)")
+    v = vec.reshape(-1, vec.shape[-1]).to(dev).float().contiguous()
+    b = batch.reshape(-1, batch.shape[-1]).to(dev).float().contiguous()
+    n, m, dim = v.shape[0], b.shape[0], v.shape[1]
+    seg_off = torch.arange(n + 1, dtype=torch.int32, device=dev)
+    scratch = torch.empty((n + m) * dim, dtype=torch.float32, device=dev)
+    out = torch.empty(n, m, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().sugar_cohort_scores(v.data_ptr(), dim, seg_off.data_ptr(), n, b.data_ptr(), m, scratch.data_ptr(),
+                                             out.data_ptr(), _stream(dev)), "sugar_cohort_scores")
+    return out.cpu().numpy()
+
+
+def ztnorm(scores, cohort, nTop=None):
+    """
+    ZT-norm (sugar/scores.py:219-266), host-side as in the reference: per utterance the mean / population std of its
+    cohort scores -- with nTop the ascending-sorted scores WITHOUT their first nTop entries (nTop > 0: `value[nTop:]`) or
+    only the first |nTop| (nTop < 0: `value[:-nTop]`), exactly as written there -- then z-norm with the enrol statistics
+    followed by t-norm with the test statistics, each skipped where the std is 0.  scores: DataFrame / mapping with
+    columns score / enroll / test; cohort: score_cohorts' return value or any {utterance: ndarray}.  Returns float64.
+    """
+    orig, enr, tst = _trial_columns(scores)
+    mean, std = {}, {}
+    for key in set(enr) | set(tst):
+        value = np.asarray(cohort[key])
+        if nTop is not None:
+            value = np.sort(value, kind="mergesort")
+            value = value[:-nTop] if nTop < 0 else value[nTop:]
+        mean[key], std[key] = value.mean(), value.std()
+    out = np.empty(len(orig), dtype=np.float64)
+    for i, (s, e, t) in enumerate(zip(orig, enr, tst)):
+        z = (s - mean[e]) / std[e] if std[e] != 0 else s
+        out[i] = (z - mean[t]) / std[t] if std[t] != 0 else z
+    return out
+
+
+def normalize_scores(scores, s_min=0, s_max=1):
+    """sugar/scores.py:402-420 (sklearn's minmax_scale): scores mapped linearly onto [s_min, s_max]."""
+    x = np.asarray(scores, dtype=np.float64)
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    span = np.where(hi - lo == 0, 1.0, hi - lo)               # sklearn: a constant column keeps scale 1
+    return (x - lo) / span * (s_max - s_min) + s_min
+
+
+def save_sctr(sc, tr, score_file, root_dir="", scale=True):
+    """sugar/scores.py:27-36: one "%.6f enroll test" line per trial (scores min-max scaled to [0, 1] when `scale`),
+    `root_dir` stripped from both names; refuses to overwrite."""
+    import os
+    assert not os.path.exists(score_file)
+    if scale is True:
+        sc = normalize_scores(sc)
+    with open(score_file, "w") as f:
+        for s, t in zip(sc, tr):
+            f.write("%.6f %s %s\n" % (s, t[0].replace(root_dir, ""), t[1].replace(root_dir, "")))
+
+
+def load_sctr(score_file):
+    """sugar/scores.py:38-53: (scores, [[enroll, test], ...]) of a file written by save_sctr."""
+    sc, tr = [], []
+    with open(score_file, "r") as f:
+        for line in f:
+            s, t1, t2 = line.split(" ")
+            sc.append(float(s))
+            tr.append([t1, t2.replace("\n", "")])
+    return sc, tr

@@ -443,3 +443,29 @@ def shard_indices(n_items, rank, world, weights=None):
         return list(range(rank, n_items, world))
     order = sorted(range(n_items), key=lambda i: -weights[i])
     return sorted(order[rank::world])
+
+
+def length_normalize(ivectors, scaleup=False):
+    """
+    sugar/vectors.py:25-60 (host helper, torch tensor or ndarray in -> same kind out): vectors divided by their 2-norm
+    (by norm / sqrt(dim) with `scaleup`), plus the mean and the population std of that ratio.
+    """
+    import numpy as np
+    if isinstance(ivectors, torch.Tensor):
+        ratio = ivectors.norm(p=2, dim=-1, keepdim=True)
+    elif isinstance(ivectors, np.ndarray):
+        ratio = np.linalg.norm(ivectors, ord=2, axis=-1, keepdims=True)
+    else:
+        raise TypeError("length_normalize expects a torch.Tensor or a numpy.ndarray")
+    if scaleup is True:
+        ratio = ratio / float(np.sqrt(ivectors.shape[-1]))
+    ratio_avg = ratio.mean()
+    ratio_std = ((ratio ** 2).mean() - ratio_avg ** 2) ** 0.5
+    return ivectors / ratio, ratio_avg, ratio_std
+
+
+def vector_transform(vectors, transform=None):
+    """sugar/vectors.py:157-178: {key: transform(value)}, or a shallow copy of the dict when transform is None."""
+    if transform is None:
+        return {k: v for k, v in vectors.items()}
+    return {k: transform(v) for k, v in vectors.items()}
