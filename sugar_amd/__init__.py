@@ -8,8 +8,9 @@ from .dynamictdnn import (DynamicTDNN, TDNNPath, TDNNSubnet, ecapa_tdnn, specfic
                           tdnn16m4g, tdnn26m7g)
 from .graphs import GraphedEmbedder
 from .latency import TDNNLatency, latency
-from .metrics import calculate_eer, calculate_mindcf
-from .models import SpeakerModel, WrappedModel, batch_forward, bn_state_dict, checkpoint2backbone, veri_validate
+from .metrics import calculate_eer, calculate_mindcf, calculate_val
+from .models import (SpeakerModel, WrappedModel, batch_forward, bn_state_dict, checkpoint2backbone, keep_params,
+                     load_bn_state_dict, veri_validate)
 from .scores import (asnorm, calculate_score, load_sctr, normalize_scores, save_sctr, score_batch, score_cohorts,
                      score_trials, snorm, ztnorm)
 from .transforms import LogMelFbanks, PreEmphasis
@@ -22,5 +23,5 @@ __all__ = ["DynamicTDNN", "TDNNPath", "TDNNSubnet", "ecapa_tdnn", "specfic_tdnn"
            "calculate_score", "score_trials", "LogMelFbanks", "PreEmphasis", "extract_vectors", "veri_validate", "batch_forward",
            "calculate_eer", "calculate_mindcf", "score_cohorts", "asnorm", "snorm", "TDNNLatency", "latency", "evaluate_subnets",
            "shard_configs", "gather_results", "PackedUtterances", "VectorTable",
-           "ztnorm", "score_batch", "normalize_scores", "save_sctr", "load_sctr", "length_normalize", "vector_transform",
+           "calculate_val", "load_bn_state_dict", "keep_params", "ztnorm", "score_batch", "normalize_scores", "save_sctr", "load_sctr", "length_normalize", "vector_transform",
            "ArchCoder", "config2d", "AccuracyPredictor", "MinimizeError", "GPULatencyConstraint", "ea_solve", "GraphedEmbedder"]

@@ -22,6 +22,16 @@ from .waveforms import loadWAV
 __all__ = ["txt2list", "Utterance", "VerificationTrials"]
 
 
+def txt2dict(txtfile, txtroot=""):
+    """Lines "speaker path" -> {speaker: [txtroot/path, ...]} in file order (sugar/database.py:39-69)."""
+    utts = {}
+    with open(txtfile, "r") as f:
+        for line in f:
+            spk, path = line.split(" ")
+            utts.setdefault(spk, []).append(os.path.join(txtroot, path.replace("\n", "")))
+    return utts
+
+
 def txt2list(txtfile, txtroot=""):
     """List file, one "[speaker ]path" per line -> [txtroot/path, ...] (sugar/database.py:71-103)."""
     with open(txtfile, "r") as f:

@@ -87,3 +87,29 @@ def calculate_mindcf(y, y_score, p_target=0.01, c_miss=1, c_fa=1):
         return both[best, 0], both[best, 1]
     fnrs, fprs, thresholds = compute_error_rates(y_score, y)
     return compute_mindcf(fnrs, fprs, thresholds, p_target=p_target, c_miss=c_miss, c_fa=c_fa)
+
+
+def calculate_val(y, y_score, far=1e-3):
+    """
+    Validation rate at a false-accept rate (sugar/metrics.py:221-281): bisection on the threshold until the interval is
+    below far * 1e-3, VAL = accepted targets / targets at the upper end; a 2-d score array gives the column with the
+    SMALLEST VAL (`argmin`, as written there).  Returns (VAL, threshold).
+    """
+    y, y_score = np.asarray(y), np.asarray(y_score)
+    assert y_score.ndim == 1 or y_score.ndim == 2
+    if y_score.ndim == 2:
+        vt = np.array([calculate_val(y, y_score[:, i], far=far) for i in range(y_score.shape[1])])
+        best = vt[:, 0].argmin()
+        return vt[best, 0], vt[best, 1]
+    lo, hi = y_score.min(), y_score.max()
+    nontar = y == 0
+    n_nontar = nontar.sum()
+    while (hi - lo) >= far * 1e-3:
+        mid = (lo + hi) / 2
+        if (nontar & (y_score >= mid)).sum() / n_nontar > far:
+            lo = mid
+        else:
+            hi = mid
+    assert (nontar & (y_score >= hi)).sum() / n_nontar <= far
+    target = y == 1
+    return y[target & (y_score >= hi)].sum() / target.sum(), hi

@@ -183,6 +183,32 @@ def bn_state_dict(model, removed_prefix=""):
     return out
 
 
+def load_bn_state_dict(model, state_dict):
+    """Load a BN-only state dict (the 'bn' entry of a *.bn.tar file) into a cloned subnet: every entry must match a
+    tensor of the model by name and size, else AssertionError naming the rest (sugar/utils/utility.py:26-42)."""
+    own = model.state_dict()
+    unloaded = []
+    for name, param in state_dict.items():
+        if name in own and own[name].size() == param.size():
+            own[name].copy_(param)
+        else:
+            unloaded.append(name)
+    assert len(unloaded) == 0, f"{unloaded} NOT Loaded!"
+    model.load_state_dict(own)
+
+
+def keep_params(state_dict_path, params_path):
+    """Strip optimizer / scheduler / lr_step from a training checkpoint: what a `*.torchparams` file, the supernet file of
+    from_pretrained, holds (sugar/utils/utility.py:67-75).  Refuses to overwrite.  The checkpoint is read with
+    weights_only=True (tensors and plain containers only)."""
+    assert os.path.exists(state_dict_path) and not os.path.exists(params_path)
+    state_dict = torch.load(state_dict_path, map_location="cpu", weights_only=True)
+    assert "state_dict" in state_dict
+    for k in ("optimizer", "scheduler", "lr_step"):
+        del state_dict[k]
+    torch.save(state_dict, params_path)
+
+
 def veri_validate(loader, model, args=None, tboard=None, norm=True, p_target=0.05, device="cuda:0", mode="cosine",
                   ret_info=False, vectors=None):
     """

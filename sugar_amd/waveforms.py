@@ -10,7 +10,7 @@ import random
 import numpy as np
 from scipy.io import wavfile
 
-__all__ = ["round_down", "load_wav", "loadWAV"]
+__all__ = ["round_down", "load_wav", "loadWAV", "wav_segment"]
 
 
 def round_down(num, divisor):
@@ -51,3 +51,14 @@ def loadWAV(path, num_samples=48000, mode_eval=False, num_eval=6, sample_rate=16
     else:
         wave = audio[None]
     return wave.astype(np.float32)
+
+
+def wav_segment(audio, num_samples=48000, noverlap=None):
+    """
+    sugar/waveforms.py:118-146: wrap-pad the waveform by num_samples - len % num_samples (a whole extra segment when the
+    length already divides, as written there) and cut it into rows of num_samples, hop `noverlap` (default: num_samples).
+    """
+    audio = audio[0] if audio.ndim == 2 else audio
+    audio = np.pad(audio, (0, num_samples - (audio.shape[0] % num_samples)), mode="wrap")
+    hop = num_samples if noverlap is None else noverlap
+    return np.stack([audio[i:i + num_samples] for i in range(0, audio.shape[0], hop)], axis=0)
