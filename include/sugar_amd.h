@@ -205,6 +205,11 @@ int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, i
                      const void* d_x, const void* d_x2, void* d_y, const int32_t* d_row_off, int B, int64_t R,
                      int t_max, int dtype, void* stream);
 
+/* HOST memory only.  Replaces: Utterance.collate_fn's torch.cat of the segment stacks (sugar/database.py:144-158) when the
+ * waveforms live in host memory: h_dst (typically pinned) <- the n float32 segments h_src[i][0 .. h_len[i]) back to
+ * back, copied by n_threads threads over equal byte ranges.  No GPU call; the caller then issues ONE host-to-device copy. */
+int sugar_pack_segments(const float* const* h_src, const int64_t* h_len, int n, float* h_dst, int n_threads);
+
 /* Replaces: F.normalize(vec, p=2, dim=1) (sugar/vectors.py:108-109,143-144), in place, float32 [n][dim]. */
 int sugar_l2norm(float* d_x, int64_t n, int dim, void* stream);
 

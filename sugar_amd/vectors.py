@@ -107,9 +107,9 @@ class PackedUtterances:
 class _HostFeed:
     """
     Host-fed batches for extract_vectors' list path (the reference feeds its forward from DataLoader workers,
-    sugar/vectors.py:126-153): a producer thread packs batch k + 1 into a PINNED staging buffer (`workers` threads copy
-    the segments side by side: torch's CPU copy releases the GIL) and sends it over PCIe on a copy stream while the GPU
-    computes batch k.  Three slots (pinned buffer + device buffer + two events each), so packing, the PCIe copy and the
+    sugar/vectors.py:126-153): a producer thread packs batch k + 1 into a PINNED staging buffer (ONE native call,
+    sugar_pack_segments: `workers` threads over equal byte ranges, no interpreter lock) and sends it over PCIe on a
+    copy stream while the GPU computes batch k.  Three slots (pinned buffer + device buffer + two events each), so packing, the PCIe copy and the
     compute of three consecutive batches overlap; a slot is reused once the forward that read it has finished.
     Without this the list path issued one synchronous pageable-memory copy per segment (4 874 of them for BASELINE
     config 4) from the thread that also launches the kernels.
@@ -121,30 +121,35 @@ class _HostFeed:
         import queue
         import threading
         import time
-        from concurrent.futures import ThreadPoolExecutor
         from .transforms import BatchPlan
         self.device = device
         cap = max(sum(lengths[i] for i in b) for b in batches)
-        self.pinned = [torch.empty(cap, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)]
+        # (pin_memory=True: straight from torch's caching pinned allocator; `.pin_memory()` on a fresh tensor copies the
+        # whole buffer once more -- 0.5 GB of memcpy per call for three 168 MB slots, a third of config 4's wall-clock)
+        self.pinned = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(self.SLOTS)]
         self.dev = [torch.empty(cap, dtype=torch.float32, device=device) for _ in range(self.SLOTS)]
         self.h2d_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.free = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.copy_stream = torch.cuda.Stream(device)
         self.q = queue.Queue()
         self.sem = threading.Semaphore(self.SLOTS)                # slots the consumer has handed back (see done())
-        self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+        self.workers = max(1, int(workers))
         self._stop = False
         self.stats = {"pack_s": 0.0, "wait_slot_s": 0.0, "bytes": 0}   # host-side seconds of the producer (diagnostics)
 
-        def pack(dst, pieces):
-            # float32 segments move with a plain memmove through ctypes, which drops the GIL for the call: the worker
-            # threads then really copy side by side (tensor.copy_ from 8 threads measured 13 GB/s, one thread 10.8)
-            base = dst.data_ptr()
-            for off, seg in pieces:
-                if seg.dtype == torch.float32 and seg.is_contiguous():
-                    ctypes.memmove(base + 4 * off, seg.data_ptr(), 4 * seg.numel())
-                else:
-                    dst[off:off + seg.numel()].copy_(seg.reshape(-1))
+        def pack(dst, batch):
+            """All float32 contiguous segments of the batch in ONE native call (sugar_pack_segments: n_jobs threads over
+            equal byte ranges, no interpreter lock held); anything else falls back to tensor.copy_ per segment."""
+            if all(segs[i].dtype == torch.float32 and segs[i].is_contiguous() for i in batch):
+                n = len(batch)
+                src = (ctypes.c_void_p * n)(*[segs[i].data_ptr() for i in batch])
+                lens = (ctypes.c_int64 * n)(*[lengths[i] for i in batch])
+                _lib.check(_lib.lib().sugar_pack_segments(src, lens, n, dst.data_ptr(), self.workers), "sugar_pack_segments")
+                return
+            off = 0
+            for i in batch:
+                dst[off:off + lengths[i]].copy_(segs[i].reshape(-1))
+                off += lengths[i]
 
         def produce():
             try:
@@ -158,12 +163,8 @@ class _HostFeed:
                         if k >= self.SLOTS:
                             self.free[s].synchronize()            # ... and the forward that read it has finished
                         t1 = time.perf_counter()
-                        pieces, off = [], 0
-                        for i in batch:
-                            pieces.append((off, segs[i]))
-                            off += lengths[i]
-                        n = max(1, min(len(pieces), self.pool._max_workers))
-                        list(self.pool.map(lambda part: pack(self.pinned[s], part), [pieces[j::n] for j in range(n)]))
+                        off = sum(lengths[i] for i in batch)
+                        pack(self.pinned[s], batch)
                         self.stats["wait_slot_s"] += t1 - t0
                         self.stats["pack_s"] += time.perf_counter() - t1
                         self.stats["bytes"] += 4 * off
@@ -198,7 +199,6 @@ class _HostFeed:
         self._stop = True
         self.sem.release()                                        # a producer waiting for a slot sees _stop
         self.thread.join()
-        self.pool.shutdown(wait=True)
 
 
 def _dist_info(rank, world_size, shard):

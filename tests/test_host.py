@@ -173,3 +173,20 @@ def test_packed_fp32_forms_are_confined_to_the_probe_cleared_ones():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if os.path.exists(hipcc):
         assert build._check_packed_forms(hipcc, "fbank.hip") > 0
+
+
+def test_pack_segments_host_only():
+    """sugar_pack_segments (host memory, no GPU call): ragged float32 segments packed back to back by 1 .. 64 threads over
+    equal byte ranges -- boundaries fall inside segments -- equal torch.cat; null / negative arguments are refused."""
+    import ctypes
+    segs = [torch.randn(n) for n in (5, 70000, 1, 333333, 99999, 257)]
+    n, want = len(segs), torch.cat(segs)
+    src = (ctypes.c_void_p * n)(*[s.data_ptr() for s in segs])
+    lens = (ctypes.c_int64 * n)(*[s.numel() for s in segs])
+    for nt in (1, 3, 8, 64, 0):
+        dst = torch.full((want.numel() + 8,), -7.0)
+        assert _lib.lib().sugar_pack_segments(src, lens, n, dst.data_ptr(), nt) == 0
+        assert torch.equal(dst[:-8], want) and (dst[-8:] == -7.0).all(), nt
+    assert _lib.lib().sugar_pack_segments(None, lens, n, dst.data_ptr(), 4) < 0
+    bad = (ctypes.c_int64 * n)(*([-1] + [1] * (n - 1)))
+    assert _lib.lib().sugar_pack_segments(src, bad, n, dst.data_ptr(), 4) < 0
