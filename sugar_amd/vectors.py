@@ -95,10 +95,32 @@ class PackedUtterances:
         self.files, self.counts, self.n_rows = files, counts, len(segs)
         lengths = [int(s.numel()) for s in segs]
         self.batches = []
-        for batch in plan_batches(lengths, max(1, batch_size), max_frames):
-            flat = torch.cat([segs[i].reshape(-1).to(self.device, non_blocking=True).float() for i in batch])
+        host = bool(segs) and all((not s.is_cuda) and s.dtype == torch.float32 and s.is_contiguous() for s in segs)
+        batches = list(plan_batches(lengths, max(1, batch_size), max_frames))
+        if host:         # one native pack into pinned memory + ONE copy per batch instead of one pageable copy per segment
+            import ctypes
+            cap = max(sum(lengths[i] for i in b) for b in batches)
+            pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(min(2, len(batches)))]
+            copied = [None] * len(pins)                # the event after the last copy out of each staging buffer
+        for k, batch in enumerate(batches):
+            if host:
+                n, total = len(batch), sum(lengths[i] for i in batch)
+                pin = pins[k % len(pins)]
+                if copied[k % len(pins)] is not None:
+                    copied[k % len(pins)].synchronize()
+                src = (ctypes.c_void_p * n)(*[segs[i].data_ptr() for i in batch])
+                lens = (ctypes.c_int64 * n)(*[lengths[i] for i in batch])
+                _lib.check(_lib.lib().sugar_pack_segments(src, lens, n, pin.data_ptr(), 8), "sugar_pack_segments")
+                flat = torch.empty(total, dtype=torch.float32, device=self.device)
+                flat.copy_(pin[:total], non_blocking=True)
+                copied[k % len(pins)] = torch.cuda.Event()
+                copied[k % len(pins)].record()
+            else:
+                flat = torch.cat([segs[i].reshape(-1).to(self.device, non_blocking=True).float() for i in batch])
             self.batches.append((torch.tensor(batch, device=self.device), flat, BatchPlan([lengths[i] for i in batch],
                                                                                           self.device)))
+        if host:
+            torch.cuda.current_stream(self.device).synchronize()
 
     def __len__(self):
         return len(self.files)
