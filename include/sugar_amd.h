@@ -279,7 +279,7 @@ const char* sugar_profile_stage_name(int stage);
  * variable SUGAR_<NAME IN CAPITALS> when the library first needs one; afterwards only these calls change them
  * (atomics: safe while other threads launch).  Names: "gemm_wreg_min_r" (default 19200: frames from which the 512-channel
  * 1x1 convs use the weights-in-registers GEMM), "gemm_uniform", "gemm_no_pingpong", "generic_res2", "res2_max_t",
- * "generic_layer1", "gemm_no_persist", "res2_no_db" (switches, default 0), "gemm_no_quad" (0 / 1 / 2: schedule of the
+ * "generic_layer1", "gemm_no_persist", "res2_no_db", "recal_separate_stats" (switches, default 0), "gemm_no_quad" (0 / 1 / 2: schedule of the
  * persistent GEMM). */
 int sugar_tune_set(const char* name, int64_t value);
 int sugar_tune_get(const char* name, int64_t* value);

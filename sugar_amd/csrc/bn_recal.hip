@@ -220,25 +220,29 @@ void bn_state_free(BNState* st) {
   *st = BNState();
 }
 
-int bn_workspace_doubles(int c_max) {
-  const int narrow = BN_BLOCKS_NARROW * 2 * BN_NARROW_C, wide = BN_BLOCKS * 2 * c_max;
-  return wide > narrow ? wide : narrow;
+int64_t bn_workspace_doubles(int c_max, int64_t R) {
+  const int64_t narrow = BN_BLOCKS_NARROW * 2 * BN_NARROW_C, wide = BN_BLOCKS * 2 * c_max;
+  const int64_t fused = (int64_t)conv_stat_blocks(R) * 2 * c_max;      // partials written by the producing conv
+  const int64_t m = wide > narrow ? wide : narrow;
+  return m > fused ? m : fused;
 }
 
 int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, float momentum, double* d_part,
-                    float* d_scale, float* d_shift, int dtype, hipStream_t s) {
+                    float* d_scale, float* d_shift, int dtype, hipStream_t s, int part_blocks) {
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(C % E == 0 && C <= st.n && ld % E == 0 && ((uintptr_t)d_z & 15) == 0 && R > 0,
                   "bn_batch: bad shape C %d ld %d", C, ld);
   const bool narrow = C <= BN_NARROW_C;
   const int cap = narrow ? BN_BLOCKS_NARROW : BN_BLOCKS;
-  const int nblk = (int)(R < 32 * (int64_t)cap ? ceil_div(R, 32) : cap);
-  const dim3 grid((unsigned)ceil_div(C / E, 8), (unsigned)nblk);
-  if (dtype == SUGAR_F32)
-    hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)d_z, ld, R, C, d_part);
-  else
-    hipLaunchKernelGGL(bn_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_z, ld, R, C, d_part);
-  SUGAR_LAUNCH_CHECK();
+  const int nblk = part_blocks > 0 ? part_blocks : (int)(R < 32 * (int64_t)cap ? ceil_div(R, 32) : cap);
+  if (part_blocks <= 0) {
+    const dim3 grid((unsigned)ceil_div(C / E, 8), (unsigned)nblk);
+    if (dtype == SUGAR_F32)
+      hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)d_z, ld, R, C, d_part);
+    else
+      hipLaunchKernelGGL(bn_stats_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_z, ld, R, C, d_part);
+    SUGAR_LAUNCH_CHECK();
+  }
   if (narrow)
     hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((unsigned)ceil_div(C, 8)), dim3(256), 0, s, d_part, nblk, C, (double)R,
                        st.gamma(), st.beta(), st.mean(), st.var(), momentum, d_scale, d_shift);

@@ -74,6 +74,7 @@ enum {
   TUNE_GEMM_NO_PERSIST,       // != 0: the wide GEMM as one workgroup per tile (no persistent loop)
   TUNE_GEMM_NO_QUAD,          // persistent wide GEMM: 0 quadrant schedule in two phases per k-tile, 2 in four phases, 1 two-half ping-pong
   TUNE_RES2_NO_DB,            // != 0: Res2 chain kernel without the double-buffered u tile (two barriers per step)
+  TUNE_RECAL_SEPARATE_STATS,  // != 0: BN recalibration computes every BatchNorm's statistics in a pass of its own (A/B, tests)
   TUNE_COUNT
 };
 int64_t tune_get(int key);
@@ -189,11 +190,21 @@ struct ConvIO {
   void* y2 = nullptr;        // optional duplicate store of columns >= y2_from (pointer has NO column offset)
   int ldy2 = 0;
   int y2_from = 0;
+  // BN recalibration: when set, the conv also writes the statistics partials of its output that launch_bn_batch
+  // would otherwise compute in a pass of its own: [conv_stat_blocks(R)][sum | sum of squares][stat_c] doubles.  Only
+  // convs for which conv_emits_stats() is true (the generic kernel), with stat_c == the conv's cout.
+  double* stat_part = nullptr;
+  int stat_c = 0;
 };
 
 int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s);
 // true when launch_conv sends this conv to the LDS-DMA 1x1 GEMMs of conv1x1.hip, which do not read d_rowseg
 bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype);
+// can launch_conv fill ConvIO::stat_part for this conv (C = the BatchNorm's channel count), and in how many row blocks?
+inline bool conv_emits_stats(const ConvLayer& L, const ConvIO& io, int dtype, int C) {
+  return !gemm1x1_eligible(L, io, dtype) && C == L.cout && !(L.flags & EPI_TANH);
+}
+int conv_stat_blocks(int64_t R);
 
 // gemm_wreg_kernel with two MFMA tiles per wave (CM = 2): row i of tile m is output channel 8 (i / 4) + 4 m + i % 4 of
 // the wave's 32, so that lane (fr, fq), which holds rows 4 fq .. 4 fq + 3 of both tiles, owns channels 8 fq .. 8 fq + 7
@@ -284,10 +295,12 @@ struct BNState {            // device f32 [4][n]: gamma | beta | running_mean | 
 };
 int bn_state_create(BNState* st, const SugarBN* bn, int c, int n_packed, const int* map);
 void bn_state_free(BNState* st);
-int bn_workspace_doubles(int c_max);
-// z [R][C] (row stride ld, compute dtype) <- train-mode BN of z, in place; running statistics of st updated
+int64_t bn_workspace_doubles(int c_max, int64_t R);
+// z [R][C] (row stride ld, compute dtype) <- train-mode BN of z, in place; running statistics of st updated.
+// part_blocks > 0: d_part already holds that many row blocks of partials (written by the conv that produced z,
+// ConvIO::stat_part) and the statistics pass over z is skipped.
 int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, float momentum, double* d_part,
-                    float* d_scale, float* d_shift, int dtype, hipStream_t s);
+                    float* d_scale, float* d_shift, int dtype, hipStream_t s, int part_blocks = 0);
 // x [B][ld] f32 <- train-mode BN over the B rows, in place (st.n channels)
 int launch_bn_rows(float* d_x, int ld, int B, const BNState& st, float momentum, hipStream_t s);
 // (scale, shift) of eval-mode BN from the running statistics

@@ -29,6 +29,8 @@ struct ConvArgs {
   int ldx, ldx2, ldy, ldy2, y2_from;
   int R, cout, cin_p, ktaps, dil, k_pad, flags;
   int n_co_tiles, n_row_tiles;
+  double* stat;   // STATS: per-(row tile, channel) sum and sum of squares of the stored outputs (bn_recal.hip's partials)
+  int stat_c;     //        channels of that table
 };
 
 template <typename T>
@@ -75,7 +77,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
 }
 
-template <typename T, int BCO, int BR>
+// Fixed-order reduce-scatter over the 32 lanes of one half wave (lanes that share `lane >> 5`): every lane brings 16
+// values; afterwards lane l holds, for value index (l >> 1) & 15, the sum over the 32 lanes (both lanes of a pair hold
+// the same number).  16 cross-lane moves instead of 16 x 5 for one butterfly per value.
+template <int HALF>
+__device__ __forceinline__ void reduce_scatter_step(float (&v)[16], int l) {
+  constexpr int MASK = 2 * HALF;                     // lane bit that picks the half a lane keeps
+  const bool up = l & MASK;
+#pragma unroll
+  for (int k = 0; k < HALF; ++k) {
+    const float keep = up ? v[k + HALF] : v[k], send = up ? v[k] : v[k + HALF];
+    v[k] = keep + __shfl_xor(send, MASK);
+  }
+}
+__device__ __forceinline__ float reduce_scatter32(float (&v)[16], int l) {
+  reduce_scatter_step<8>(v, l);                      // (explicit steps: as one loop over `half` the array indices were
+  reduce_scatter_step<4>(v, l);                      //  not compile-time constants and became 900 selects)
+  reduce_scatter_step<2>(v, l);
+  reduce_scatter_step<1>(v, l);
+  return v[0] + __shfl_xor(v[0], 1);
+}
+
+// STATS (BN recalibration, bn_recal.hip): the epilogue also leaves, per row tile and output channel, the sum and the sum
+// of squares of the values it STORES (after the rounding to T) in a.stat -- the partial table bn_finalize_kernel adds
+// up -- so that train-mode BatchNorm needs no pass of its own over the tensor for its statistics.
+template <typename T, int BCO, int BR, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int BKE = 8 * EPC;          // K elements per tile
@@ -184,6 +210,45 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   T* __restrict__ y = (T*)a.y;
   T* __restrict__ y2 = (T*)a.y2;
   const bool relu = a.flags & EPI_RELU, affine = a.flags & EPI_AFFINE, tanh_ = a.flags & EPI_TANH;
+  if constexpr (STATS) {
+    // Statistics first, straight from the accumulators and branch-free (inside the store loop below the compiler turned
+    // every update into a select per guarding branch: 900 v_cndmask, 20.7 us against 13.1 for the 64-channel Res2 step).
+    // Rows past R were loaded as zeros and stay 0 through ReLU, so they need no mask; channels past cout are never
+    // written out.  Lanes of one half wave (fh) hold 32 frames of the same 16 channels per MFMA tile: reduce-scatter
+    // over them; the two row halves of the workgroup (wr) are added through LDS (free since the barrier that closed
+    // the K loop).
+    float* red = (float*)smem;                       // [wr][sum | sum of squares][BCO]
+    const float lo = relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float ssum[16], ssq[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float t = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float x = to_f32(from_f32<T>(fmaxf(acc[m][n][e], lo)));      // the value the loop below stores
+          t += x;
+          t2 = fmaf(x, x, t2);
+        }
+        ssum[e] = t;
+        ssq[e] = t2;
+      }
+      const float s1 = reduce_scatter32(ssum, frow), s2 = reduce_scatter32(ssq, frow);
+      const int e = (frow >> 1) & 15;
+      const int ch = wco * (BCO / 2) + m * 32 + 8 * (e >> 2) + 4 * fh + (e & 3);
+      if (!(frow & 1)) {
+        red[(wr * 2 + 0) * BCO + ch] = s1;
+        red[(wr * 2 + 1) * BCO + ch] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BCO && co_base + tid < a.cout) {
+      double* p = a.stat + (size_t)row_tile * 2 * a.stat_c + co_base + tid;
+      p[0] = (double)red[0 * BCO + tid] + (double)red[2 * BCO + tid];
+      p[a.stat_c] = (double)red[1 * BCO + tid] + (double)red[3 * BCO + tid];
+    }
+  }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int r = r_base + wr * (BR / 2) + n * 32 + frow;
@@ -220,19 +285,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int BCO, int BR>
-static int launch_conv_t(const ConvArgs& a0, hipStream_t s) {
-  ConvArgs a = a0;
-  a.n_co_tiles = (int)ceil_div(a.cout, BCO);
-  a.n_row_tiles = (int)ceil_div(a.R, BR);
+constexpr int CONV_BR = 128;      // frames per tile of every instantiation below = rows per block of the STATS table
+
+template <typename T, int BCO, int BR, bool STATS>
+static int launch_conv_ts(const ConvArgs& a, hipStream_t s) {
   const size_t smem = 2 * (BCO + BR) * 128;
   static OptInMask opted{0};   // > 64 KiB never needed here, but keep the opt-in explicit, once per device
-  if (int rc = lds_opt_in((const void*)conv_gemm_kernel<T, BCO, BR>, (int)smem, &opted)) return rc;
+  if (int rc = lds_opt_in((const void*)conv_gemm_kernel<T, BCO, BR, STATS>, (int)smem, &opted)) return rc;
   const int grid = a.n_co_tiles * a.n_row_tiles;
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BCO, BR>), dim3(grid), dim3(256), smem, s, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BCO, BR, STATS>), dim3(grid), dim3(256), smem, s, a);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
 }
+
+template <typename T, int BCO, int BR>
+static int launch_conv_t(const ConvArgs& a0, hipStream_t s) {
+  static_assert(BR == CONV_BR, "conv_stat_blocks assumes one tile height");
+  ConvArgs a = a0;
+  a.n_co_tiles = (int)ceil_div(a.cout, BCO);
+  a.n_row_tiles = (int)ceil_div(a.R, BR);
+  return a.stat ? launch_conv_ts<T, BCO, BR, true>(a, s) : launch_conv_ts<T, BCO, BR, false>(a, s);
+}
+
+int conv_stat_blocks(int64_t R) { return (int)ceil_div(R, CONV_BR); }
 
 bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype);
 int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t s);
@@ -242,6 +317,8 @@ int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int6
   SUGAR_CHECK_ARG(R > 0 && R < (1ll << 31), "conv: bad row count %lld", (long long)R);
   SUGAR_CHECK_ARG(L.w && io.x && io.y && d_rowseg, "conv: null pointer");
   SUGAR_CHECK_ARG(((uintptr_t)io.x & 15) == 0 && io.ldx % epc == 0, "conv: activation pointer / ld must be 16-byte aligned");
+  SUGAR_CHECK_ARG(!io.stat_part || (!gemm1x1_eligible(L, io, dtype) && io.stat_c == L.cout && !(L.flags & EPI_TANH)),
+                  "conv: statistics asked of a conv that cannot emit them (see conv_emits_stats)");
   if (gemm1x1_eligible(L, io, dtype)) return launch_gemm1x1(L, io, R, s);   // wide 1x1 convs: LDS-DMA 256^2 GEMM
   SUGAR_CHECK_ARG(L.cin_p % epc == 0 && io.ldx % epc == 0 && io.ldy % 4 == 0 && L.cout % 4 == 0,
                   "conv: channel counts must be multiples of the 16-byte chunk (cin_p %d ldx %d ldy %d cout %d)",
@@ -256,6 +333,7 @@ int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int6
   a.ldx = io.ldx; a.ldx2 = io.ldx2; a.ldy = io.ldy; a.ldy2 = io.ldy2; a.y2_from = io.y2_from;
   a.R = (int)R; a.cout = L.cout; a.cin_p = L.cin_p; a.ktaps = L.ktaps; a.dil = L.dil; a.k_pad = L.k_pad;
   a.flags = L.flags; a.n_co_tiles = 0; a.n_row_tiles = 0;
+  a.stat = io.stat_part; a.stat_c = io.stat_c;
   const bool small = L.n_pad <= 64;
   SUGAR_CHECK_ARG(L.n_pad % (small ? 64 : 128) == 0, "conv: n_pad %d not tile aligned", L.n_pad);
   if (dtype == SUGAR_F32) return small ? launch_conv_t<float, 64, 128>(a, s) : launch_conv_t<float, 128, 128>(a, s);

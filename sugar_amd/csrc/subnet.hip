@@ -74,8 +74,8 @@ struct Prof {
 // ---- tunables: environment read once, then atomics ----
 static const char* kTuneNames[TUNE_COUNT] = {"gemm_wreg_min_r", "gemm_uniform", "gemm_no_pingpong", "generic_res2",
                                              "res2_max_t", "generic_layer1", "gemm_no_persist", "gemm_no_quad",
-                                             "res2_no_db"};
-static const int64_t kTuneDefaults[TUNE_COUNT] = {19200, 0, 0, 0, 0, 0, 0, 0, 0};
+                                             "res2_no_db", "recal_separate_stats"};
+static const int64_t kTuneDefaults[TUNE_COUNT] = {19200, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static std::atomic<int64_t> g_tune[TUNE_COUNT];
 static std::once_flag g_tune_once;
 
@@ -369,7 +369,7 @@ static Workspace plan(const SugarSubnet* n, int B, int64_t R, void* base) {
   w.poolpart = (float*)take(pool_part_floats(n->pool, B, R) * 4);
   w.tailpart = (float*)take((int64_t)tail_splits(n->tail) * B * n->embed * 4);
   const int cbn = n->c0p > n->midp_max ? n->c0p : n->midp_max;
-  w.bnpart = (double*)take((int64_t)bn_workspace_doubles(cbn) * 8);
+  w.bnpart = (double*)take(bn_workspace_doubles(cbn, R) * 8);
   w.bnscale = (float*)take((int64_t)cbn * 4);
   w.bnshift = (float*)take((int64_t)cbn * 4);
   w.embpre = (float*)take((int64_t)B * n->embed * 4);
@@ -502,6 +502,17 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
   auto bn = [&](void* z, int ld, int C, const BNState& st) {
     return launch_bn_batch(z, ld, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s);
   };
+  // conv -> ReLU, then train-mode BN of its output in place.  The generic conv kernel leaves the BatchNorm's
+  // statistics partials behind (ConvIO::stat_part) and the BN skips its own pass over the tensor; the LDS-DMA GEMMs
+  // (bf16 1x1 convs of 512+ channels) do not, and their BN runs bn_stats_kernel as before.
+  auto conv_bn = [&](const ConvLayer& L, ConvIO io, int C, const BNState& st) {
+    const ConvLayer raw = raw_conv(L);
+    const bool fused = !tune_get(TUNE_RECAL_SEPARATE_STATS) && conv_emits_stats(raw, io, dt, C);
+    if (fused) { io.stat_part = w.bnpart; io.stat_c = C; }
+    if (int rc2 = launch_conv(raw, io, w.rowseg, R, dt, s)) return rc2;
+    return launch_bn_batch(io.y, io.ldy, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s,
+                           fused ? conv_stat_blocks(R) : 0);
+  };
   if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc;
 
   {
@@ -513,9 +524,9 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
     } else {
       ConvIO io;
       io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
-      if ((rc = launch_conv(l1, io, w.rowseg, R, dt, s))) return rc;
+      if ((rc = conv_bn(n->layer1, io, n->c0p, n->bn_layer1))) return rc;
     }
-    if ((rc = bn(w.S, n->c0p, n->c0p, n->bn_layer1))) return rc;
+    if (layer1_as_tap_gemm(n) && (rc = bn(w.S, n->c0p, n->c0p, n->bn_layer1))) return rc;
   }
 
   const int ldcat = n->depth * n->c0p;
@@ -525,16 +536,13 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
     const int ldin = i == 0 ? n->c0p : ldcat;
     ConvIO f;
     f.x = xin; f.ldx = ldin; f.y = w.mid1; f.ldy = b.midp;
-    if ((rc = launch_conv(raw_conv(b.first), f, w.rowseg, R, dt, s)) || (rc = bn(w.mid1, b.midp, b.midp, b.bn_first)))
-      return rc;
+    if ((rc = conv_bn(b.first, f, b.midp, b.bn_first))) return rc;
     for (int j = 0; j < SUGAR_RES2_SCALE - 1; ++j) {                              // dynamictdnn.py:294-299
       ConvIO r;
       r.x = col(w.mid1, (int64_t)j * b.wp); r.ldx = b.midp;
       if (j > 0) { r.x2 = col(w.mid2, (int64_t)(j - 1) * b.wp); r.ldx2 = b.midp; }
       r.y = col(w.mid2, (int64_t)j * b.wp); r.ldy = b.midp;
-      if ((rc = launch_conv(raw_conv(b.res[j]), r, w.rowseg, R, dt, s)) ||
-          (rc = bn(r.y, b.midp, b.wp, b.bn_res[j])))
-        return rc;
+      if ((rc = conv_bn(b.res[j], r, b.wp, b.bn_res[j]))) return rc;
     }
     // the 8th split passes through (:300-301): the normalised first_conv columns
     const int64_t c7 = (int64_t)(SUGAR_RES2_SCALE - 1) * b.wp;
@@ -542,8 +550,7 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
                                (size_t)b.wp * esz, (size_t)R, hipMemcpyDeviceToDevice, s));
     ConvIO l;
     l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
-    if ((rc = launch_conv(raw_conv(b.last), l, w.rowseg, R, dt, s)) || (rc = bn(w.ybuf, n->c0p, n->c0p, b.bn_last)))
-      return rc;
+    if ((rc = conv_bn(b.last, l, n->c0p, b.bn_last))) return rc;
     if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.separt, w.sescale, dt, s))) return rc;
     void* out = col(w.cat, (int64_t)i * n->c0p);
     if ((rc = launch_se_apply(w.ybuf, n->c0p, w.sescale, n->c0p, w.S, n->c0p, out, ldcat, i + 1 < n->depth, row_off, B,

@@ -280,7 +280,7 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
     """
     rank, world = _dist_info(rank, world_size, shard)
     if world > 1:
-        return _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank, world)
+        return _extract_sharded(model, datalst, norm, device, n_jobs, batch_size, max_frames, rank, world)
     packed = datalst if isinstance(datalst, PackedUtterances) else None
     device = packed.device if packed is not None else torch.device(device)
     if device.type != "cuda":
@@ -350,7 +350,7 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
     return VectorTable(files, counts, out)
 
 
-def _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank, world):
+def _extract_sharded(model, datalst, norm, device, n_jobs, batch_size, max_frames, rank, world):
     """extract_vectors on `world` ranks: shard -> embed -> exchange -> the complete table on every rank."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != world:
@@ -387,7 +387,7 @@ def _extract_sharded(model, datalst, norm, device, batch_size, max_frames, rank,
         return VectorTable(packed.files, packed.counts, out)
     n = len(datalst)
     mine = shard_indices(n, rank, world, getattr(datalst, "lengths", None))
-    local = extract_vectors(model, _Subset(datalst, mine), norm, device, 0, batch_size, max_frames)
+    local = extract_vectors(model, _Subset(datalst, mine), norm, device, n_jobs, batch_size, max_frames)
     # two collectives: one object gather of the host-side bookkeeping (item indices, names, segment counts -- which
     # also gives every rank's row count), one all_gather_into_tensor of the vectors
     meta = [None] * world

@@ -103,3 +103,34 @@ def test_reset_bn_and_errors():
     smodel = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sup, transform=sugar_amd.LogMelFbanks())).to(dev).train()
     with pytest.raises(sugar_amd._lib.SugarError):         # supernet in train(): clone first
         smodel(synth.waveforms(2, 8000, seed=1).to(dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_conv_epilogue_statistics_equal_the_separate_pass(precision):
+    """The generic conv kernel's epilogue leaves the BatchNorm partial sums behind (ConvIO::stat_part); with
+    recal_separate_stats=1 every BatchNorm runs bn_stats_kernel over the stored tensor instead.  Both sum the SAME stored
+    values (f32 partials of 128 rows, then doubles, against doubles throughout), on a ragged batch whose last row tile is
+    partial.  f32: every running statistic and the embeddings agree to f32 rounding.  bf16: the first BatchNorm fed by a
+    fused conv (Res2 step 0 of block 0; layer1 and first_conv run on the LDS-DMA GEMMs in both modes) agrees to f32
+    rounding; behind it a 1e-7 change of a scale moves bf16 roundings of the normalised tensor, so later layers are held
+    to the bf16 path's own noise level only."""
+    dev = torch.device("cuda", 0)
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    lens = [16000, 23456, 48000, 9999, 31000]
+    wavs = [synth.waveforms(1, n, seed=40 + i)[0].to(dev) for i, n in enumerate(lens)]
+    out = {}
+    for sep in (0, 1):
+        sub = sup.clone(layout.BASE).set_precision(precision)
+        spk = sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks()).to(dev)
+        spk.train()
+        with sugar_amd._lib.tuned(recal_separate_stats=sep):
+            emb = spk.embed_ragged(wavs, normalize=False)
+        spk.eval()
+        out[sep] = (emb.cpu().numpy(), {k: v.clone() for k, v in sub.state_dict().items() if "running" in k})
+    tight, loose = 2e-6, (2e-6 if precision == "fp32" else 2e-2)
+    first = ("layer1.bn.", "blocks.0.first_conv.bn.", "blocks.0.resconv.convs.0.bn.")
+    assert _rel(out[0][0], out[1][0]) < 50 * loose
+    for k in out[0][1]:
+        assert _rel(out[0][1][k].numpy(), out[1][1][k].numpy()) < (tight if k.startswith(first) else loose), k
