@@ -190,20 +190,19 @@ struct ConvIO {
   void* y2 = nullptr;        // optional duplicate store of columns >= y2_from (pointer has NO column offset)
   int ldy2 = 0;
   int y2_from = 0;
-  // BN recalibration: when set, the conv also writes the statistics partials of its output that launch_bn_batch
-  // would otherwise compute in a pass of its own: [conv_stat_blocks(R)][sum | sum of squares][stat_c] doubles.  Only
-  // convs for which conv_emits_stats() is true (the generic kernel), with stat_c == the conv's cout.
+  // BN recalibration: when set, the conv also leaves the statistics partials of its output that launch_bn_batch would
+  // otherwise compute in a pass of its own, [row blocks][sum | sum of squares][stat_c] doubles (stat_cap: doubles the
+  // table holds), if its kernel can (the generic kernel and the weights-in-registers GEMM, stat_c == the conv's cout);
+  // launch_conv reports the row blocks written through `stat_blocks` (0: none, run the statistics pass).
   double* stat_part = nullptr;
   int stat_c = 0;
+  int64_t stat_cap = 0;
 };
 
-int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s);
+int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s,
+                int* stat_blocks = nullptr);
 // true when launch_conv sends this conv to the LDS-DMA 1x1 GEMMs of conv1x1.hip, which do not read d_rowseg
 bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype);
-// can launch_conv fill ConvIO::stat_part for this conv (C = the BatchNorm's channel count), and in how many row blocks?
-inline bool conv_emits_stats(const ConvLayer& L, const ConvIO& io, int dtype, int C) {
-  return !gemm1x1_eligible(L, io, dtype) && C == L.cout && !(L.flags & EPI_TANH);
-}
 int conv_stat_blocks(int64_t R);
 
 // gemm_wreg_kernel with two MFMA tiles per wave (CM = 2): row i of tile m is output channel 8 (i / 4) + 4 m + i % 4 of
@@ -220,8 +219,10 @@ int launch_pad_rows(const ConvLayer& L, const void* d_x, void* d_xpad, const int
                     hipStream_t s);
 int64_t gemm_taps_orow_ints(const ConvLayer& L, int B, int64_t R);   // int32 entries of the output-row map d_orow
 // orow_ready: d_orow already holds the map (the fused front-end wrote it); otherwise a small kernel builds it first
+// d_stat / stat_c / stat_io: as ConvIO::stat_part / stat_c and, in: stat_cap, out: the row blocks written (0: none)
 int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, void* d_y, int ldy, const int32_t* d_row_off,
-                     int B, int64_t R, int t_max, hipStream_t s, bool orow_ready = false);
+                     int B, int64_t R, int t_max, hipStream_t s, bool orow_ready = false, double* d_stat = nullptr,
+                     int stat_c = 0, int64_t* stat_io = nullptr);
 
 // Pack a reference-layout conv weight [cout][cin][k] (host f32) into ConvLayer storage with an internal channel
 // permutation / padding: out_map[o] = packed output row of reference channel o, in_map[i] = packed input

@@ -50,6 +50,9 @@ struct Gemm1x1Args {
   // gemm_wreg_kernel over the PADDED row space of a tap conv (layer1): GEMM row q reads its K vector at x + q * ldx and
   // stores to output row orow[q] (-1: a row between two utterances, nothing to store).  nullptr: output row = q.
   const int32_t* orow = nullptr;
+  // gemm_wreg_kernel<..., STATS> (BN recalibration): [P frame ranges][sum | sum of squares][stat_c] doubles of the stored outputs
+  double* stat = nullptr;
+  int stat_c = 0;
 };
 
 constexpr int TK = 64;
@@ -755,9 +758,14 @@ constexpr int WR_TN = 64, WR_SUB = WR_TN * 128;   // a [64 frames x 64 k] sub-ti
 // pieces at the row pitch, four times the write requests); with two waves per SIMD that costs nothing measurable and
 // frees 40 KiB of LDS for deeper stages (K = 512: SK 2 -> 4, layer1: SK 1 -> 7), a lone wave per SIMD
 // (pooling.linear1) stalls on it: 74.5 vs 69 us, so that instantiation keeps the staging.
-template <int KC, int CM, int SK, int NW = 16 / CM, bool STAGED = false>
+// STATS (BN recalibration): every lane also keeps the running sum and sum of squares of the 8 channels it stores, over
+// all frames of the workgroup's range (16 VGPRs, ~100 VALU per tile); at the end the 16 lanes that share the channels are
+// added up with four DPP steps and the range's (sum, sum of squares) go to a.stat -- the partial table
+// bn_finalize_kernel reads (bn_recal.hip) -- so the BatchNorm behind the conv needs no statistics pass of its own.
+template <int KC, int CM, int SK, int NW = 16 / CM, bool STAGED = false, bool STATS = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args a, int n_half, int n_slabs, int P) {
   static_assert(KC % SK == 0, "whole stages per tile");
+  static_assert(!(STATS && STAGED), "statistics come from the direct epilogue");
   static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
   constexpr int DI = 8 / NW, SLAB = 16 * CM * NW;      // DMA instructions per wave and sub-tile; channels per workgroup
   constexpr int WR_NS = 12 / SK + 1, WR_D = WR_NS - 1, WR_STAGE = SK * WR_SUB, KS = KC / SK, H = 2 * SK;
@@ -775,7 +783,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   constexpr bool HALVES = NW == 8;
   const int n_unit = HALVES ? n_half : (n_half + 1) >> 1, hs = HALVES ? 1 : 2;
   const int h0 = hs * (int)((int64_t)p * n_unit / P), h1 = hs * (int)((int64_t)(p + 1) * n_unit / P);
-  if (h0 >= h1) return;
+  if (h0 >= h1) {
+    if constexpr (STATS) {                            // an empty range still owns a row of the table
+      const int c = slab * SLAB + wv * (CM * 16) + (lane & 31);
+      if (c < a.cout) a.stat[((size_t)p * 2 + (lane >> 5)) * a.stat_c + c] = 0.0;
+    }
+    return;
+  }
   const int f0 = h0 * (WR_TN / 2), q_end = min(h1 * (WR_TN / 2), a.R);   // first frame of the range, one past its last
   const int NTL = (h1 - h0 + 1) >> 1;                 // tiles of this workgroup, the last one HALF if the count is odd
   const bool odd = (h1 - h0) & 1;
@@ -878,6 +892,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
   // 64 contiguous bytes per frame and wave (what the transposition through LDS used to build, without the LDS trip)
   static_assert(CM == 2, "the direct epilogue pairs two MFMA tiles per wave");
   unsigned char* ep = smem + WR_NS * WR_STAGE + wv * EPW;   // STAGED: this wave's [64 frames][32 channels] staging
+  float ssum[STATS ? 8 : 1], ssq[STATS ? 8 : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
+  }
   auto epilogue = [&](int lt) {                         // lt: tile of this workgroup, frames f0 + 64 lt ..
     const int32_t* om = omap + (lt & 3) * WR_TN;
     const int tf = f0 + lt * WR_TN;
@@ -911,6 +930,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
       if (q < q_end && r >= 0 && co < a.cout && !((WREG_KNOCK & 8) && v[0] != 0x12345u)) {
         *(u32x4*)(a.y + (size_t)r * a.ldy + co) = v;
         if (a.y2 && co >= a.y2_from) *(u32x4*)(a.y2 + (size_t)r * a.ldy2 + co) = v;
+      }
+      if constexpr (STATS) {                            // unconditional updates of what was stored (0 for the rows that were not)
+        const bool live = q < q_end && r >= 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = live ? (float)o[i] : 0.f;
+          ssum[i] += x;
+          ssq[i] = fmaf(x, x, ssq[i]);
+        }
       }
     }
     if (STAGED) {
@@ -978,19 +1006,56 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_wreg_kernel(Gemm1x1Args 
       epilogue(NTL - 1);
     }
   }
+  if constexpr (STATS) {
+    // the 16 lanes fr = 0 .. 15 of a group fq hold different frames of the same 8 channels: quad, quad pair, half row,
+    // row -- a fixed order, every lane ends with the same totals
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float s1 = ssum[i], s2 = ssq[i];
+      s1 += dpp_row_f32<0xB1>(s1);  s2 += dpp_row_f32<0xB1>(s2);     // quad_perm [1,0,3,2]
+      s1 += dpp_row_f32<0x4E>(s1);  s2 += dpp_row_f32<0x4E>(s2);     // quad_perm [2,3,0,1]
+      s1 += dpp_row_f32<0x141>(s1); s2 += dpp_row_f32<0x141>(s2);    // row_half_mirror
+      s1 += dpp_row_f32<0x140>(s1); s2 += dpp_row_f32<0x140>(s2);    // row_mirror
+      ssum[i] = s1;
+      ssq[i] = s2;
+    }
+    const int co = co_w + 8 * fq;
+    if (fr == 0 && co < a.cout) {
+      double* pp = a.stat + (size_t)p * 2 * a.stat_c + co;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        pp[i] = (double)ssum[i];
+        pp[a.stat_c + i] = (double)ssq[i];
+      }
+    }
+  }
 }
 
+// stat_io (with a.stat set): in = doubles the table a.stat can hold; out = the row blocks written (the frame ranges P),
+// or 0 when this launch could not leave the statistics behind
 template <int KC, int CM, int SK, int NW = 16 / CM, bool STAGED = false>
-int launch_wreg(const Gemm1x1Args& a, hipStream_t s) {
+int launch_wreg(const Gemm1x1Args& a, hipStream_t s, int64_t* stat_io = nullptr) {
   // the ring + (STAGED) the waves' output staging + the output-row map slots
   constexpr int smem = (12 / SK + 1) * SK * WR_SUB + (STAGED ? NW * WR_TN * (CM * 32 + 16) : 0) + 4 * WR_TN * 4;
-  static OptInMask opted{0};
-  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK, NW, STAGED>, smem, &opted)) return rc;
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu)) return rc;
   const int n_slabs = (int)ceil_div(a.cout, 16 * CM * NW), n_half = (int)ceil_div(a.R, WR_TN / 2);
   int P = n_cu / n_slabs / 8 * 8;
   if (P < 8) P = 8;
+  if constexpr (!STAGED) {
+    if (a.stat && stat_io && a.stat_c == a.cout && (int64_t)P * 2 * a.stat_c <= *stat_io) {
+      static OptInMask opted_s{0};
+      if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK, NW, false, true>, smem, &opted_s)) return rc;
+      hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK, NW, false, true>), dim3(n_slabs * P), dim3(64 * NW), smem, s, a, n_half,
+                         n_slabs, P);
+      SUGAR_LAUNCH_CHECK();
+      *stat_io = P;
+      return SUGAR_OK;
+    }
+  }
+  if (stat_io) *stat_io = 0;
+  static OptInMask opted{0};
+  if (int rc = lds_opt_in((const void*)gemm_wreg_kernel<KC, CM, SK, NW, STAGED>, smem, &opted)) return rc;
   hipLaunchKernelGGL((gemm_wreg_kernel<KC, CM, SK, NW, STAGED>), dim3(n_slabs * P), dim3(64 * NW), smem, s, a, n_half, n_slabs, P);
   SUGAR_LAUNCH_CHECK();
   return SUGAR_OK;
@@ -1066,7 +1131,7 @@ int64_t gemm_taps_orow_ints(const ConvLayer& L, int B, int64_t R) {
 }
 
 int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, void* d_y, int ldy, const int32_t* d_row_off,
-                     int B, int64_t R, int t_max, hipStream_t s, bool orow_ready) {
+                     int B, int64_t R, int t_max, hipStream_t s, bool orow_ready, double* d_stat, int stat_c, int64_t* stat_io) {
   const int halo = (L.ktaps - 1) / 2, C = L.cin_p;
   SUGAR_CHECK_ARG(((uintptr_t)d_xpad & 15) == 0 && ((uintptr_t)d_y & 15) == 0 && ldy % 8 == 0, "gemm_taps: unaligned buffers");
   Gemm1x1Args a;
@@ -1086,8 +1151,10 @@ int launch_gemm_taps(const ConvLayer& L, const void* d_xpad, int32_t* d_orow, vo
     a.R = (int)(R + (int64_t)2 * halo * B);           // GEMM rows = padded rows
     a.orow = d_orow;
     a.wfrag = (const bf16*)L.wfrag;
-    return launch_wreg<7, 2, 7, 8>(a, s);
+    a.stat = d_stat; a.stat_c = stat_c;
+    return launch_wreg<7, 2, 7, 8>(a, s, stat_io);
   }
+  if (stat_io) *stat_io = 0;
   a.n_co_tiles = (int)ceil_div(L.cout, 128);
   a.row_off = d_row_off; a.B = B; a.xmap = 2 * halo;
   return launch_variant<128, 128, 2>(a, s);
@@ -1102,7 +1169,8 @@ bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype) {
          ((uintptr_t)io.y & 15) == 0 && (!io.y2 || (io.ldy2 % 8 == 0 && ((uintptr_t)io.y2 & 15) == 0 && io.y2_from % 8 == 0));
 }
 
-int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t s) {
+int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t s, int64_t* stat_io) {
+  if (stat_io && !(io.stat_part && L.cout > 128 && L.cin_p <= 768)) *stat_io = 0;   // only the K = 512 weights-in-registers launch below
   Gemm1x1Args a;
   a.x = (const bf16*)io.x; a.w = (const bf16*)L.w; a.y = (bf16*)io.y; a.y2 = (bf16*)io.y2;
   a.scale = L.scale; a.shift = L.shift;
@@ -1131,8 +1199,10 @@ int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t 
       // DMA stream runs across tiles, 0.180 / 0.169 against 0.167 / 0.155)
       if (L.wfrag && R >= wreg_min_r && a.K == 512 && L.cout % 256 == 0) {
         a.wfrag = (const bf16*)L.wfrag;
-        return launch_wreg<8, 2, 4>(a, s);
+        a.stat = io.stat_part; a.stat_c = io.stat_c;
+        return launch_wreg<8, 2, 4>(a, s, stat_io);
       }
+      if (stat_io) *stat_io = 0;
       a.n_co_tiles = (int)ceil_div(L.cout, 128);
       return launch_variant<128, 128, 2>(a, s);
     }

@@ -310,16 +310,23 @@ static int launch_conv_t(const ConvArgs& a0, hipStream_t s) {
 int conv_stat_blocks(int64_t R) { return (int)ceil_div(R, CONV_BR); }
 
 bool gemm1x1_eligible(const ConvLayer& L, const ConvIO& io, int dtype);
-int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t s);
+int launch_gemm1x1(const ConvLayer& L, const ConvIO& io, int64_t R, hipStream_t s, int64_t* stat_io);
 
-int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s) {
+int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int64_t R, int dtype, hipStream_t s,
+                int* stat_blocks) {
+  int64_t stat_io = io.stat_cap;
+  if (stat_blocks) *stat_blocks = 0;
   const int epc = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(R > 0 && R < (1ll << 31), "conv: bad row count %lld", (long long)R);
   SUGAR_CHECK_ARG(L.w && io.x && io.y && d_rowseg, "conv: null pointer");
   SUGAR_CHECK_ARG(((uintptr_t)io.x & 15) == 0 && io.ldx % epc == 0, "conv: activation pointer / ld must be 16-byte aligned");
-  SUGAR_CHECK_ARG(!io.stat_part || (!gemm1x1_eligible(L, io, dtype) && io.stat_c == L.cout && !(L.flags & EPI_TANH)),
-                  "conv: statistics asked of a conv that cannot emit them (see conv_emits_stats)");
-  if (gemm1x1_eligible(L, io, dtype)) return launch_gemm1x1(L, io, R, s);   // wide 1x1 convs: LDS-DMA 256^2 GEMM
+  SUGAR_CHECK_ARG(!io.stat_part || (stat_blocks && !(L.flags & (EPI_TANH | EPI_AFFINE))),
+                  "conv: statistics need a plain conv -> ReLU epilogue and a place for the block count");
+  if (gemm1x1_eligible(L, io, dtype)) {                                     // wide 1x1 convs: LDS-DMA GEMMs
+    const int rc = launch_gemm1x1(L, io, R, s, io.stat_part ? &stat_io : nullptr);
+    if (stat_blocks && io.stat_part) *stat_blocks = (int)stat_io;
+    return rc;
+  }
   SUGAR_CHECK_ARG(L.cin_p % epc == 0 && io.ldx % epc == 0 && io.ldy % 4 == 0 && L.cout % 4 == 0,
                   "conv: channel counts must be multiples of the 16-byte chunk (cin_p %d ldx %d ldy %d cout %d)",
                   L.cin_p, io.ldx, io.ldy, L.cout);
@@ -333,7 +340,10 @@ int launch_conv(const ConvLayer& L, const ConvIO& io, const int2* d_rowseg, int6
   a.ldx = io.ldx; a.ldx2 = io.ldx2; a.ldy = io.ldy; a.ldy2 = io.ldy2; a.y2_from = io.y2_from;
   a.R = (int)R; a.cout = L.cout; a.cin_p = L.cin_p; a.ktaps = L.ktaps; a.dil = L.dil; a.k_pad = L.k_pad;
   a.flags = L.flags; a.n_co_tiles = 0; a.n_row_tiles = 0;
-  a.stat = io.stat_part; a.stat_c = io.stat_c;
+  // the statistics table of the generic kernel: one row block per 128-frame tile
+  const bool stats = io.stat_part && io.stat_c == L.cout && (int64_t)conv_stat_blocks(R) * 2 * io.stat_c <= io.stat_cap;
+  a.stat = stats ? io.stat_part : nullptr; a.stat_c = io.stat_c;
+  if (stats) *stat_blocks = conv_stat_blocks(R);
   const bool small = L.n_pad <= 64;
   SUGAR_CHECK_ARG(L.n_pad % (small ? 64 : 128) == 0, "conv: n_pad %d not tile aligned", L.n_pad);
   if (dtype == SUGAR_F32) return small ? launch_conv_t<float, 64, 128>(a, s) : launch_conv_t<float, 128, 128>(a, s);

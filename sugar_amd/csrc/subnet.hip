@@ -499,34 +499,35 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
   const int64_t esz = dt == SUGAR_F32 ? 4 : 2;
   int rc;
   auto col = [&](void* p, int64_t c) { return (void*)((char*)p + c * esz); };
-  auto bn = [&](void* z, int ld, int C, const BNState& st) {
-    return launch_bn_batch(z, ld, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s);
-  };
-  // conv -> ReLU, then train-mode BN of its output in place.  The generic conv kernel leaves the BatchNorm's
-  // statistics partials behind (ConvIO::stat_part) and the BN skips its own pass over the tensor; the LDS-DMA GEMMs
-  // (bf16 1x1 convs of 512+ channels) do not, and their BN runs bn_stats_kernel as before.
+  // conv -> ReLU, then train-mode BN of its output in place.  The generic conv kernel and the weights-in-registers
+  // GEMM leave the BatchNorm's statistics partials behind (ConvIO::stat_part) and the BN skips its own pass over the
+  // tensor; the tile GEMMs (short batches, 1024-channel convs) do not, and their BN runs bn_stats_kernel as before.
+  const bool fuse_stats = !tune_get(TUNE_RECAL_SEPARATE_STATS);
+  const int cbn = n->c0p > n->midp_max ? n->c0p : n->midp_max;
+  const int64_t stat_cap = bn_workspace_doubles(cbn, R);
   auto conv_bn = [&](const ConvLayer& L, ConvIO io, int C, const BNState& st) {
-    const ConvLayer raw = raw_conv(L);
-    const bool fused = !tune_get(TUNE_RECAL_SEPARATE_STATS) && conv_emits_stats(raw, io, dt, C);
-    if (fused) { io.stat_part = w.bnpart; io.stat_c = C; }
-    if (int rc2 = launch_conv(raw, io, w.rowseg, R, dt, s)) return rc2;
-    return launch_bn_batch(io.y, io.ldy, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s,
-                           fused ? conv_stat_blocks(R) : 0);
+    int blocks = 0;
+    if (fuse_stats) { io.stat_part = w.bnpart; io.stat_c = C; io.stat_cap = stat_cap; }
+    if (int rc2 = launch_conv(raw_conv(L), io, w.rowseg, R, dt, s, &blocks)) return rc2;
+    return launch_bn_batch(io.y, io.ldy, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s, blocks);
   };
   if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc;
 
   {
     const ConvLayer l1 = raw_conv(n->layer1);
     if (layer1_as_tap_gemm(n)) {                      // the eval path's tap GEMM with the affine switched off
+      int64_t stat_io = stat_cap;
       if ((rc = launch_pad_rows(l1, feats, w.featp, row_off, B, R, t_max, s)) ||
-          (rc = launch_gemm_taps(l1, w.featp, w.orow, w.S, n->c0p, row_off, B, R, t_max, s, false)))
+          (rc = launch_gemm_taps(l1, w.featp, w.orow, w.S, n->c0p, row_off, B, R, t_max, s, false,
+                                 fuse_stats ? w.bnpart : nullptr, n->c0p, fuse_stats ? &stat_io : nullptr)) ||
+          (rc = launch_bn_batch(w.S, n->c0p, R, n->c0p, n->bn_layer1, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s,
+                                fuse_stats ? (int)stat_io : 0)))
         return rc;
     } else {
       ConvIO io;
       io.x = feats; io.ldx = n->in_feats; io.y = w.S; io.ldy = n->c0p;
       if ((rc = conv_bn(n->layer1, io, n->c0p, n->bn_layer1))) return rc;
     }
-    if (layer1_as_tap_gemm(n) && (rc = bn(w.S, n->c0p, n->c0p, n->bn_layer1))) return rc;
   }
 
   const int ldcat = n->depth * n->c0p;
