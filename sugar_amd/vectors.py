@@ -7,6 +7,7 @@ a DataLoader (:126-153).  Here both become packed batches: utterances are sorted
 bounded by ``batch_size`` utterances and ``max_frames`` frames, each batch is ONE fused C-ABI call
 (fbank + TDNN + L2 norm) with no padding, and results are scattered back to the reference's per-file layout.
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -57,6 +58,11 @@ class VectorTable(dict):
     matrix on the device), plus that matrix (`.matrix`), the files in order (`.files`) and the segment offsets
     (`.seg_off`, int32 [n_files + 1] on the device), so that score_trials / score_cohorts use the table as it is instead
     of concatenating thousands of views again.
+
+    The views are made on first use: building 4 874 tensor views up front cost 22 ms of host time per call -- more than
+    the GPU needs to embed the list with a small subnet, and the NAS sweep (which scores through `.matrix`) was bound by
+    it.  `table[file]`, `in`, `len`, iteration and `.keys()` work from the file index; `.items()` / `.values()` and any
+    mutation materialise every view first, after which this is an ordinary dict.
     """
 
     def __init__(self, files, counts, matrix):
@@ -64,12 +70,81 @@ class VectorTable(dict):
         self.files = files
         self.counts = list(counts)
         self.matrix = matrix
-        seg, start = [0], 0
-        for f, n in zip(files, counts):            # segments of one file are contiguous rows
-            self[f] = matrix[start:start + n]
-            start += n
-            seg.append(start)
-        self.seg_off = torch.tensor(seg, dtype=torch.int32).to(matrix.device)
+        seg = np.zeros(len(self.counts) + 1, dtype=np.int32)
+        np.cumsum(np.asarray(self.counts, dtype=np.int64), out=seg[1:])
+        self._seg = seg.tolist()                       # segments of one file are contiguous rows
+        self._where = {f: i for i, f in enumerate(files)}     # a file listed twice: its last rows, as a dict built in order
+        self.seg_off = torch.from_numpy(seg).to(matrix.device)
+
+    def _fill(self):
+        if self._where is not None:
+            where, self._where = self._where, None
+            views = self.matrix.split(self.counts) if self.counts else ()
+            for f, i in where.items():
+                dict.__setitem__(self, f, views[i])
+
+    def __getitem__(self, f):
+        if self._where is None or dict.__contains__(self, f):
+            return dict.__getitem__(self, f)
+        i = self._where[f]                             # KeyError for an unknown file, as a dict
+        v = self.matrix[self._seg[i]:self._seg[i + 1]]
+        dict.__setitem__(self, f, v)
+        return v
+
+    def get(self, f, default=None):
+        return self[f] if f in self else default
+
+    def __contains__(self, f):
+        return f in self._where if self._where is not None else dict.__contains__(self, f)
+
+    def __len__(self):
+        return len(self._where) if self._where is not None else dict.__len__(self)
+
+    def __iter__(self):
+        return iter(self._where) if self._where is not None else dict.__iter__(self)
+
+    def keys(self):
+        return self._where.keys() if self._where is not None else dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def copy(self):
+        return dict(self.items())
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __reduce__(self):
+        return (dict, (dict(self.items()),))
+
+    def __repr__(self):
+        return "VectorTable(%d files, %d x %d matrix on %s)" % (len(self), self.matrix.shape[0], self.matrix.shape[1],
+                                                               self.matrix.device)
+
+    def _mutating(name):
+        def method(self, *args, **kwargs):
+            self._fill()
+            return getattr(dict, name)(self, *args, **kwargs)
+        method.__name__ = name
+        return method
+
+    __setitem__ = _mutating("__setitem__")
+    __delitem__ = _mutating("__delitem__")
+    pop = _mutating("pop")
+    popitem = _mutating("popitem")
+    update = _mutating("update")
+    setdefault = _mutating("setdefault")
+    clear = _mutating("clear")
+    del _mutating
 
 
 class PackedUtterances:
