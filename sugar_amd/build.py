@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv_gemm.hip", "conv1x1.hip", "res2.hip","fbank.hip", "se_pool.hip", "pool.hip", "score.hip", "bn_recal.hip", "asnorm.hip", "subnet.hip", "hostpack.hip"]
+SOURCES = ["conv_gemm.hip", "conv1x1.hip", "res2.hip","fbank.hip", "se_pool.hip", "pool.hip", "score.hip", "bn_recal.hip", "asnorm.hip", "subnet.hip", "hostpack.hip", "arena.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "sugar_amd.h")]
 LIB = os.path.join(HERE, "libsugar_amd.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

@@ -207,15 +207,14 @@ int bn_state_create(BNState* st, const SugarBN* bn, int c, int n_packed, const i
     host[2 * (size_t)n_packed + p] = bn->running_mean[o];
     host[3 * (size_t)n_packed + p] = bn->running_var[o];
   }
-  hipError_t e = hipMalloc(&st->p, 4 * (size_t)n_packed * sizeof(float));
-  if (e == hipSuccess) e = hipMemcpy(st->p, host, 4 * (size_t)n_packed * sizeof(float), hipMemcpyHostToDevice);
+  int rc = dev_alloc(&st->p, 4 * (size_t)n_packed * sizeof(float));
+  if (!rc) rc = dev_upload(st->p, host, 4 * (size_t)n_packed * sizeof(float));
   free(host);
-  if (e != hipSuccess) { set_error("bn_state: %s", hipGetErrorString(e)); return SUGAR_EHIP; }
-  return SUGAR_OK;
+  return rc;
 }
 
 void bn_state_free(BNState* st) {
-  if (st->p) (void)hipFree(st->p);
+  dev_free(st->p);
   free(st->h_map);
   *st = BNState();
 }

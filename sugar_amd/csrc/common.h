@@ -1,6 +1,8 @@
 // Shared helpers for libsugar_amd (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -151,6 +153,36 @@ static inline uint16_t host_f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+
+// ---- device memory of packed weights (arena.hip) --------------------------------------------------
+// Inside an ArenaScope dev_alloc carves 256-byte aligned pieces out of a few large chunks owned by the arena and
+// dev_upload fills a host mirror that arena_flush sends with one asynchronous copy per chunk on a private stream;
+// dev_free ignores arena memory.  Outside a scope they are hipMalloc / hipMemcpy / hipFree.
+struct DevArena {
+  struct Chunk {
+    char* dev = nullptr;
+    char* host = nullptr;     // mirror until arena_flush
+    size_t cap = 0, used = 0;
+  };
+  std::vector<Chunk> chunks;
+};
+class ArenaScope {            // makes `a` the calling thread's arena for its lifetime
+ public:
+  explicit ArenaScope(DevArena* a);
+  ~ArenaScope();
+  ArenaScope(const ArenaScope&) = delete;
+  ArenaScope& operator=(const ArenaScope&) = delete;
+
+ private:
+  DevArena* prev_;
+};
+int dev_alloc(void** p, size_t bytes);
+template <typename T>
+inline int dev_alloc(T** p, size_t bytes) { return dev_alloc((void**)p, bytes); }
+int dev_upload(void* d_dst, const void* h_src, size_t bytes);
+void dev_free(void* p);
+int arena_flush(DevArena* a);      // copies + waits for the upload stream; the mirrors are freed
+void arena_release(DevArena* a);   // frees the chunks
 
 // ---- per-row utterance segment table ------------------------------------------------------------
 // rowseg[r] = (first row, one-past-last row) of the utterance owning row r.

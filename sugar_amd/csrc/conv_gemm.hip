@@ -380,8 +380,8 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
       }
     }
   }
-  hipError_t e = hipMalloc(&L->w, n * esz);
-  if (e == hipSuccess) e = hipMemcpy(L->w, host, n * esz, hipMemcpyHostToDevice);
+  int rc = dev_alloc(&L->w, n * esz);
+  if (!rc) rc = dev_upload(L->w, host, n * esz);
   // gemm_wreg_kernel<KC, CM, SK, NW> (conv1x1.hip) wants the weights once more in its fragment-load order: wave wv of
   // channel slab `slab` loads fragment (c, m) as one contiguous KiB, lane fq * 16 + fr holding
   // W[slab * 16 CM NW + wv * 16 CM + wreg_row(m, fr)][c * 32 + fq * 8 .. + 7] (CM = 2; wreg_row interleaves the two MFMA
@@ -395,7 +395,7 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
   } else if (dtype == SUGAR_BF16 && dil == 1 && L->k_pad == 448 && L->n_pad % 256 == 0) {
     f_cm = 2;
   }
-  if (e == hipSuccess && f_cm) {
+  if (!rc && f_cm) {
     uint16_t* frag = (uint16_t*)malloc(n * 2);
     if (!frag) { free(host); set_error("pack_conv: host alloc"); return SUGAR_ENOMEM; }
     const uint16_t* src = (const uint16_t*)host;
@@ -409,12 +409,12 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
               const int co = slab * slab_ch + wv * 16 * f_cm + wreg_row(m, lane & 15), kk = c * 32 + (lane >> 4) * 8;
               for (int q = 0; q < 8; ++q) frag[d++] = src[(size_t)co * L->k_pad + kk + q];
             }
-    e = hipMalloc(&L->wfrag, n * 2);
-    if (e == hipSuccess) e = hipMemcpy(L->wfrag, frag, n * 2, hipMemcpyHostToDevice);
+    rc = dev_alloc(&L->wfrag, n * 2);
+    if (!rc) rc = dev_upload(L->wfrag, frag, n * 2);
     free(frag);
   }
   free(host);
-  if (e != hipSuccess) { set_error("pack_conv: %s", hipGetErrorString(e)); return SUGAR_EHIP; }
+  if (rc) return rc;
   if (bn) {
     float* sc = (float*)calloc(2 * (size_t)L->n_pad, sizeof(float));
     if (!sc) { set_error("pack_conv: host alloc"); return SUGAR_ENOMEM; }
@@ -425,10 +425,10 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
       sc[po] = (float)s;
       sh[po] = (float)((double)bn->bias[o] - (double)bn->running_mean[o] * s);
     }
-    e = hipMalloc(&L->scale, 2 * (size_t)L->n_pad * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(L->scale, sc, 2 * (size_t)L->n_pad * sizeof(float), hipMemcpyHostToDevice);
+    rc = dev_alloc(&L->scale, 2 * (size_t)L->n_pad * sizeof(float));
+    if (!rc) rc = dev_upload(L->scale, sc, 2 * (size_t)L->n_pad * sizeof(float));
     free(sc);
-    if (e != hipSuccess) { set_error("pack_conv: %s", hipGetErrorString(e)); return SUGAR_EHIP; }
+    if (rc) return rc;
     L->shift = L->scale + L->n_pad;
     L->flags |= EPI_AFFINE;
   }
@@ -436,9 +436,9 @@ int pack_conv(ConvLayer* L, const float* h_w, const SugarBN* bn, int cout, int c
 }
 
 void free_conv(ConvLayer* L) {
-  if (L->w) (void)hipFree(L->w);
-  if (L->wfrag) (void)hipFree(L->wfrag);
-  if (L->scale) (void)hipFree(L->scale);
+  dev_free(L->w);
+  dev_free(L->wfrag);
+  dev_free(L->scale);
   *L = ConvLayer();
 }
 

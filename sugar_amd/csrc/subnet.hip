@@ -131,43 +131,47 @@ struct SugarSubnet {
   sugar::BNState bn_layer1, bn_pool, bn_embed;
   sugar::TailLayer tail_raw;
   std::vector<float> h_linear_w, h_linear_b;
+  sugar::DevArena arena;     // every packed tensor above lives in its chunks (arena.hip)
 };
 
 namespace sugar {
 
 static int upload(float** dst, const std::vector<float>& v) {
-  SUGAR_HIP(hipMalloc(dst, v.size() * sizeof(float)));
-  SUGAR_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
-  return SUGAR_OK;
+  if (int rc = dev_alloc(dst, v.size() * sizeof(float))) return rc;
+  return dev_upload(*dst, v.data(), v.size() * sizeof(float));
 }
 
 static bool bn_ok(const SugarBN& b) { return b.weight && b.bias && b.running_mean && b.running_var; }
 
 static void destroy(SugarSubnet* n) {
-  free_conv(&n->layer1);
-  free_conv(&n->catconv);
-  free_conv(&n->pool1);
-  for (int i = 0; i < SUGAR_MAX_DEPTH; ++i) {
-    Block& b = n->blocks[i];
-    free_conv(&b.first);
-    free_conv(&b.last);
-    for (auto& r : b.res) free_conv(&r);
-    if (b.se.w1t) (void)hipFree(b.se.w1t);
-    if (b.se.b1) (void)hipFree(b.se.b1);
-    if (b.se.w2t) (void)hipFree(b.se.w2t);
-    if (b.se.b2) (void)hipFree(b.se.b2);
-    bn_state_free(&b.bn_first);
-    bn_state_free(&b.bn_last);
-    for (auto& r : b.bn_res) bn_state_free(&r);
+  {
+    ArenaScope scope(&n->arena);                       // the frees below skip what the arena owns
+    free_conv(&n->layer1);
+    free_conv(&n->catconv);
+    free_conv(&n->pool1);
+    for (int i = 0; i < SUGAR_MAX_DEPTH; ++i) {
+      Block& b = n->blocks[i];
+      free_conv(&b.first);
+      free_conv(&b.last);
+      for (auto& r : b.res) free_conv(&r);
+      dev_free(b.se.w1t);
+      dev_free(b.se.b1);
+      dev_free(b.se.w2t);
+      dev_free(b.se.b2);
+      bn_state_free(&b.bn_first);
+      bn_state_free(&b.bn_last);
+      for (auto& r : b.bn_res) bn_state_free(&r);
+    }
+    dev_free(n->pool.w2);
+    dev_free(n->tail.wt);
+    dev_free(n->tail.bias);
+    dev_free(n->tail_raw.wt);
+    dev_free(n->tail_raw.bias);
+    bn_state_free(&n->bn_layer1);
+    bn_state_free(&n->bn_pool);
+    bn_state_free(&n->bn_embed);
   }
-  if (n->pool.w2) (void)hipFree(n->pool.w2);
-  if (n->tail.wt) (void)hipFree(n->tail.wt);
-  if (n->tail.bias) (void)hipFree(n->tail.bias);
-  if (n->tail_raw.wt) (void)hipFree(n->tail_raw.wt);
-  if (n->tail_raw.bias) (void)hipFree(n->tail_raw.bias);
-  bn_state_free(&n->bn_layer1);
-  bn_state_free(&n->bn_pool);
-  bn_state_free(&n->bn_embed);
+  arena_release(&n->arena);
   delete n;
 }
 
@@ -300,8 +304,7 @@ static int create(const SugarSubnetDesc* d, int dtype, SugarSubnet* n) {
         if (dtype == SUGAR_F32) ((float*)host.data())[(size_t)c * d->bottleneck + k] = v;
         else ((uint16_t*)host.data())[(size_t)c * d->bottleneck + k] = host_f32_to_bf16(v);
       }
-    SUGAR_HIP(hipMalloc(&n->pool.w2, cnt * esz));
-    SUGAR_HIP(hipMemcpy(n->pool.w2, host.data(), cnt * esz, hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(&n->pool.w2, cnt * esz)) || (rc = dev_upload(n->pool.w2, host.data(), cnt * esz))) return rc;
     n->pool.ccat = d->ccat;
     n->pool.ccat_p = n->ccatp;
     n->pool.bott = d->bottleneck;
@@ -638,11 +641,12 @@ int sugar_subnet_create(const SugarSubnetDesc* d, int dtype, int device, SugarSu
   SUGAR_DEVICE_GUARD(device);
   SugarSubnet* n = new SugarSubnet();
   n->device = device;
-  int rc = create(d, dtype, n);
-  if (!rc && hipDeviceSynchronize() != hipSuccess) {
-    set_error("subnet_create: hipDeviceSynchronize failed");
-    rc = SUGAR_EHIP;
+  int rc;
+  {
+    ArenaScope scope(&n->arena);                       // all packed tensors into the subnet's chunks, sent in one go
+    rc = create(d, dtype, n);
   }
+  if (!rc) rc = arena_flush(&n->arena);
   if (rc) {
     destroy(n);
     return rc;

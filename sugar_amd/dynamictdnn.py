@@ -59,6 +59,25 @@ def _build_tree(root: nn.Module, shapes, init):
             node.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
 
 
+def _flat_tensors(root: nn.Module):
+    """{dotted key: parameter / buffer} of a _build_tree module, read straight from the module dicts: what
+    state_dict() returns for these hook-free trees at a tenth of its cost (311 tensors: 3 ms per call, paid per sampled
+    subnet by materialize() and again by handle())."""
+    out, stack = {}, [("", root)]
+    while stack:
+        prefix, m = stack.pop()
+        for k, t in m._parameters.items():
+            if t is not None:
+                out[prefix + k] = t
+        for k, t in m._buffers.items():
+            if t is not None:
+                out[prefix + k] = t
+        for k, c in m._modules.items():
+            if c is not None:
+                stack.append((prefix + k + ".", c))
+    return out
+
+
 def _default_init(key, shape):
     leaf = key.rsplit(".", 1)[-1]
     if leaf in ("k53", "k31", "k75"):
@@ -121,14 +140,17 @@ class TDNNSubnet(nn.Module):
     per (device, precision) and dropped whenever the parameters change (load_state_dict).
     """
 
-    def __init__(self, config, state=None, in_feats=80, out_embeds=192, precision="bf16"):
+    def __init__(self, config, state=None, in_feats=80, out_embeds=192, precision="bf16", adopt=False):
+        """state: {key: tensor} in the cloned-subnet layout (copied; `adopt=True`: taken over as they are -- the caller
+        made them for this subnet and keeps no other reference, as DynamicTDNN.materialize does)."""
         super().__init__()
         depth, ch, ks, ccat = config
         self.subnet_config = (int(depth), list(ch[:depth + 1]), list(ks[:depth + 1]), int(ccat))
         self.in_feats, self.out_embeds = in_feats, out_embeds
         self.precision = precision
         shapes = layout.subnet_shapes(self.subnet_config, in_feats, out_embeds)
-        _build_tree(self, shapes, _default_init if state is None else (lambda k, s: state[k].detach().clone()))
+        _build_tree(self, shapes, _default_init if state is None else
+                    ((lambda k, s: state[k].detach()) if adopt else (lambda k, s: state[k].detach().clone())))
         self._handles = {}       # (device index, dtype) -> c_void_p
         self._workspace = {}     # (device index, stream) -> torch.uint8 tensor
         self._device = torch.device("cpu")
@@ -137,7 +159,15 @@ class TDNNSubnet(nn.Module):
         self._generation = 0     # bumped whenever device pointers handed out earlier become invalid (release, precision)
         # parameters changed (also via a parent's load_state_dict) -> drop the packed device copies
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.release())
-        self.eval()
+        self.training = False
+
+    def train(self, mode=True):
+        """The children are inert containers of tensors (no forward of their own): the mode lives on this module only
+        (nn.Module.train walks the ~100 containers, 1.3 ms per call, several calls per sampled subnet in a sweep)."""
+        if not isinstance(mode, bool):
+            raise ValueError("training mode is expected to be boolean")
+        self.training = mode
+        return self
 
     # ---- nn.Module plumbing: parameters stay on the host; .to()/.cuda() only select the device ---------------
     def _apply(self, fn, recurse=True):
@@ -189,6 +219,12 @@ class TDNNSubnet(nn.Module):
         self._workspace = {}
         self._bn_dirty, self._bn_batches = None, 0
 
+    def drop_workspaces(self):
+        """Give the per-(device, stream) workspaces back to torch's allocator (no device synchronisation; the packed
+        weights stay).  The caller knows this subnet's kernels have run."""
+        self._generation += 1
+        self._workspace = {}
+
     def __del__(self):
         try:
             self.release()
@@ -208,7 +244,8 @@ class TDNNSubnet(nn.Module):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, self.dtype_id)
         if key not in self._handles:
-            sd = {k: v.detach().to(torch.float32).contiguous() for k, v in self.state_dict().items()
+            self.sync_bn()                             # (as state_dict() does: recalibrated statistics into the buffers)
+            sd = {k: v.detach().to(torch.float32).contiguous() for k, v in _flat_tensors(self).items()
                   if v.dtype.is_floating_point}
             depth, ch, ks, ccat = self.subnet_config
 
@@ -439,18 +476,22 @@ class DynamicTDNN(nn.Module):
         cfg = _check_config(self.config if config is None else config, self.num_blocks, self.channels,
                             self.kernel_sizes, self.catconv_channels)
         depth, ch, ks, ccat = cfg
-        sup = self.state_dict()
+        sup = {k: v.detach() for k, v in _flat_tensors(self).items()}
         c0 = ch[0]
-        out = {}
+        out = {}                                       # every entry a NEW tensor (TDNNSubnet adopts them uncopied)
 
         def bn(dst, src, sel):
             for leaf in ("weight", "bias", "running_mean", "running_var"):
-                out["%s.%s" % (dst, leaf)] = _sel(sup["%s.bn.%s" % (src, leaf)], sel).clone()
+                t = sup["%s.bn.%s" % (src, leaf)]
+                out["%s.%s" % (dst, leaf)] = t[:sel].clone() if isinstance(sel, int) else t.index_select(0, sel)
             out[dst + ".num_batches_tracked"] = sup[src + ".bn.num_batches_tracked"].clone()
 
         def conv(dst, src, in_sel, out_sel, k_active):
-            out[dst + ".weight"] = _active_conv_weight(sup[src + ".conv.weight"], in_sel, out_sel, k_active,
-                                                       sup.get(src + ".k53"), sup.get(src + ".k31"))
+            full = sup[src + ".conv.weight"]
+            w = _active_conv_weight(full, in_sel, out_sel, k_active, sup.get(src + ".k53"), sup.get(src + ".k31"))
+            if w.untyped_storage().data_ptr() == full.untyped_storage().data_ptr():
+                w = w.clone()                          # a contiguous slice of the supernet's own weight
+            out[dst + ".weight"] = w
 
         conv("layer1.conv", "layer1.conv", self.in_feats, c0, ks[0])              # dynamictdnn.py:670
         bn("layer1.bn", "layer1.bn", c0)
@@ -477,7 +518,7 @@ class DynamicTDNN(nn.Module):
         conv("pooling.linear2", "pooling.linear2", BOTTLENECK, ccat, 1)
         pool_idx = torch.arange(self.catconv_channels * 2).view(2, -1)[:, :ccat].flatten().long()   # :675
         bn("bnpool", "bnpool", pool_idx)
-        out["linear.weight"] = sup["linear.linear.weight"].index_select(1, pool_idx).clone()        # :677
+        out["linear.weight"] = sup["linear.linear.weight"].index_select(1, pool_idx)                # :677
         out["linear.bias"] = sup["linear.linear.bias"].clone()
         for leaf in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
             out["bnembed." + leaf] = sup["bnembed." + leaf].clone()
@@ -487,7 +528,7 @@ class DynamicTDNN(nn.Module):
         """DynamicTDNN.clone (dynamictdnn.py:713-730): sets the config, returns a static subnet."""
         self.config = config
         cfg, state = self.materialize()
-        sub = TDNNSubnet(cfg, state, self.in_feats, self.out_embeds, self.precision)
+        sub = TDNNSubnet(cfg, state, self.in_feats, self.out_embeds, self.precision, adopt=True)
         sub._device = self._device
         return sub
 
@@ -496,7 +537,7 @@ class DynamicTDNN(nn.Module):
         key = (layout.config_name(cfg), self.precision)
         if key not in self._subnets:
             _, state = self.materialize(cfg)
-            self._subnets[key] = TDNNSubnet(cfg, state, self.in_feats, self.out_embeds, self.precision)
+            self._subnets[key] = TDNNSubnet(cfg, state, self.in_feats, self.out_embeds, self.precision, adopt=True)
         sub = self._subnets[key]
         sub._device = self._device
         return sub

@@ -66,6 +66,14 @@ def score_trials(trials, vectors, mode="cosine", n_jobs=4):
     mode: "cosine", "norm2" or a list of them (then scores is [n_trials, len(mode)], one column per mode, :175-177).
     Returns (scores float64 ndarray, labels ndarray, [[enroll, test], ...]) like the reference.
     """
+    scores, labels, pairs = score_trials_device(trials, vectors, mode)
+    return scores.double().cpu().numpy(), labels, pairs
+
+
+def score_trials_device(trials, vectors, mode="cosine"):
+    """score_trials up to the copy to the host: (scores on the device, float32 [n_trials] or [n_trials, len(mode)]; labels
+    ndarray; [[enroll, test], ...]).  Enqueued on the current stream and not waited for, so a caller (the NAS sweep) can
+    start the next model's extraction before it reads these scores back."""
     _check_mode(mode)
     matrix = getattr(vectors, "matrix", None)
     if matrix is not None:                       # a VectorTable from extract_vectors: one matrix, offsets on the device
@@ -83,7 +91,7 @@ def score_trials(trials, vectors, mode="cosine", n_jobs=4):
         scores = torch.stack([score_pairs(vec, seg_off, e_dev, t_dev, m) for m in mode], dim=1)
     else:
         scores = score_pairs(vec, seg_off, e_dev, t_dev, mode)
-    return scores.double().cpu().numpy(), labels, pairs
+    return scores, labels, pairs
 
 
 def _fingerprint(trials):

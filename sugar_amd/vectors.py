@@ -65,16 +65,22 @@ class VectorTable(dict):
     mutation materialise every view first, after which this is an ordinary dict.
     """
 
-    def __init__(self, files, counts, matrix):
+    def __init__(self, files, counts, matrix, index=None):
+        """index: the (seg list, file -> position, seg_off on the device) of an earlier table over the same files and
+        counts (`.index`): a sweep embeds one list with many models, and the copy of seg_off from pageable memory
+        is a blocking call queued behind the whole extraction on the current stream."""
         super().__init__()
         self.files = files
         self.counts = list(counts)
         self.matrix = matrix
-        seg = np.zeros(len(self.counts) + 1, dtype=np.int32)
-        np.cumsum(np.asarray(self.counts, dtype=np.int64), out=seg[1:])
-        self._seg = seg.tolist()                       # segments of one file are contiguous rows
-        self._where = {f: i for i, f in enumerate(files)}     # a file listed twice: its last rows, as a dict built in order
-        self.seg_off = torch.from_numpy(seg).to(matrix.device)
+        if index is None:
+            seg = np.zeros(len(self.counts) + 1, dtype=np.int32)
+            np.cumsum(np.asarray(self.counts, dtype=np.int64), out=seg[1:])
+            index = (seg.tolist(),                     # segments of one file are contiguous rows
+                     {f: i for i, f in enumerate(files)},   # a file listed twice: its last rows, as a dict built in order
+                     torch.from_numpy(seg).to(matrix.device))
+        self.index = index
+        self._seg, self._where, self.seg_off = index[0], dict(index[1]), index[2]
 
     def _fill(self):
         if self._where is not None:
@@ -168,6 +174,7 @@ class PackedUtterances:
             counts.append(len(ss))
             segs.extend(ss)
         self.files, self.counts, self.n_rows = files, counts, len(segs)
+        self.table_index = None                        # VectorTable.index of the first table built over this list
         lengths = [int(s.numel()) for s in segs]
         self.batches = []
         host = bool(segs) and all((not s.is_cuda) and s.dtype == torch.float32 and s.is_contiguous() for s in segs)
@@ -422,7 +429,11 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
                     out[torch.tensor(batch, device=device)] = emb
     for lane in lanes:
         main.wait_stream(lane)
-    return VectorTable(files, counts, out)
+    if packed is None:
+        return VectorTable(files, counts, out)
+    table = VectorTable(files, counts, out, index=packed.table_index)
+    packed.table_index = table.index
+    return table
 
 
 def _extract_sharded(model, datalst, norm, device, n_jobs, batch_size, max_frames, rank, world):
@@ -459,7 +470,9 @@ def _extract_sharded(model, datalst, norm, device, n_jobs, batch_size, max_frame
         for r in range(world):
             if share[r]:
                 out[torch.cat([packed.batches[k][0] for k in share[r]])] = blocks[r]
-        return VectorTable(packed.files, packed.counts, out)
+        table = VectorTable(packed.files, packed.counts, out, index=packed.table_index)
+        packed.table_index = table.index
+        return table
     n = len(datalst)
     mine = shard_indices(n, rank, world, getattr(datalst, "lengths", None))
     local = extract_vectors(model, _Subset(datalst, mine), norm, device, n_jobs, batch_size, max_frames)

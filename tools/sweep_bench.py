@@ -46,9 +46,11 @@ sugar_amd.evaluate_subnets(sup, configs[:2], loader, device="cuda:0")     # warm
 for prefetch in (False, True, False, True):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = sugar_amd.evaluate_subnets(sup, configs, loader, device="cuda:0", prefetch=prefetch)
+    tm = {}
+    res = sugar_amd.evaluate_subnets(sup, configs, loader, device="cuda:0", prefetch=prefetch, timings=tm)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    print("   launching thread, ms per subnet: " + ", ".join("%s %.1f" % (k, v / N_SUB * 1e3) for k, v in tm.items()), flush=True)
     print("prefetch %-5s: %d subnets x %d utterances + %d trials in %.3f s  (%.1f ms per subnet, %.0f emb/s)" % (
         prefetch, N_SUB, N_UTT, N_TRIALS, dt, dt / N_SUB * 1e3, N_SUB * N_UTT / dt), flush=True)
 if os.environ.get("SWEEP_PROFILE"):
@@ -60,3 +62,30 @@ if os.environ.get("SWEEP_PROFILE"):
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+if os.environ.get("SWEEP_GPU"):
+    # where a subnet's time goes: GPU time of the extraction alone (events around extract_vectors on a packed list), the
+    # host time of clone + pack, and of scoring + metrics
+    from sugar_amd.sweep import _prepare, _TrialSnapshot, _LoaderView
+    from sugar_amd.vectors import PackedUtterances, extract_vectors
+    packed = PackedUtterances(trials.utterances, dev, batch_size=256)
+    view = _LoaderView(loader, _TrialSnapshot(trials))
+    t_gpu = t_prep = t_val = 0.0
+    for cfg in configs:
+        t0 = time.perf_counter()
+        sub = _prepare(sup, cfg, "bf16", dev)
+        t_prep += time.perf_counter() - t0
+        model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+        extract_vectors(model, packed)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        vec = extract_vectors(model, packed)
+        e1.record()
+        torch.cuda.synchronize()
+        t_gpu += e0.elapsed_time(e1) * 1e-3
+        t0 = time.perf_counter()
+        sugar_amd.veri_validate(view, model, device="cuda:0", vectors=vec)
+        t_val += time.perf_counter() - t0
+        sub.release()
+    print("per subnet: extraction on the GPU %.1f ms, clone + pack on the host %.1f ms, scoring + EER / minDCF %.1f ms" % (
+        t_gpu / N_SUB * 1e3, t_prep / N_SUB * 1e3, t_val / N_SUB * 1e3), flush=True)
