@@ -42,12 +42,16 @@ lab, a, b = synth.trial_pairs(N_UTT, N_TRIALS, seed=1)
 trials = Trials({"label": int(lab[i]), "enroll": "utt%04d.wav" % a[i], "test": "utt%04d.wav" % b[i]} for i in range(N_TRIALS))
 trials.utterances = Utts()
 loader = Loader(trials, 256)
-sugar_amd.evaluate_subnets(sup, configs[:2], loader, device="cuda:0")     # warm-up
+recal = None
+if os.environ.get("SWEEP_RECAL"):      # the full NAS loop: BN recalibration over 24 x 256 x 3 s utterances before every evaluation
+    rw = torch.randn(24, 256, 48000, device=dev)
+    recal = [(rw[i], None) for i in range(24)]
+sugar_amd.evaluate_subnets(sup, configs[:2], loader, recal_loader=recal, device="cuda:0")     # warm-up
 for prefetch in (False, True, False, True):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tm = {}
-    res = sugar_amd.evaluate_subnets(sup, configs, loader, device="cuda:0", prefetch=prefetch, timings=tm)
+    res = sugar_amd.evaluate_subnets(sup, configs, loader, recal_loader=recal, device="cuda:0", prefetch=prefetch, timings=tm)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("   launching thread, ms per subnet: " + ", ".join("%s %.1f" % (k, v / N_SUB * 1e3) for k, v in tm.items()), flush=True)
