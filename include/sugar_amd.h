@@ -107,7 +107,10 @@ typedef struct SugarSubnet SugarSubnet;   /* opaque, library-owned packed weight
  * Packs weights into MFMA-friendly [Cout][tap*Cin] panels (dtype), folds every eval-mode BN into a per-channel
  * (scale, shift) epilogue applied AFTER the ReLU (conv -> ReLU -> BN, dynamictdnn.py:183), folds
  * bnpool . linear . bnembed (dynamictdnn.py:664-665) into one affine map, and uploads to `device`.
- * This call allocates device memory and synchronises; it is not on the per-batch path. */
+ * This call allocates device memory (a few large chunks that hold every packed tensor of the subnet) and sends the
+ * weights with one asynchronous copy per chunk on a stream of the library's own, for which alone it waits: it does not
+ * touch the null stream and does not wait for other work on the device, so a host thread may pack the next model while
+ * the current one runs (sugar_amd/sweep.py).  sugar_subnet_destroy frees the chunks (hipFree waits for the device). */
 int sugar_subnet_create(const SugarSubnetDesc* h_desc, int dtype, int device, SugarSubnet** out);
 int sugar_subnet_destroy(SugarSubnet* net);
 
