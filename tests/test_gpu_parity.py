@@ -267,6 +267,51 @@ def test_subnet_sweep_equals_one_at_a_time(meta, supernet):
             assert got[key]["eer"] == eer[0] and got[key]["mindcf"] == dcf[0], (recal_loader is not None, cfg, got[key], eer, dcf)
 
 
+def test_packed_weights_arena_creates_while_busy_and_returns_its_memory(meta, supernet):
+    """sugar_subnet_create puts every packed tensor into a few chunks of its own arena and sends them with one copy on
+    a private stream (csrc/arena.hip): (a) a subnet packed on a host thread WHILE another model's extraction is queued on
+    the GPU gives the vectors of one packed on an idle GPU, bit for bit; (b) creating and releasing 24 subnets leaves
+    the device's free memory where it was (the chunks are really freed; the per-tensor hipFree calls are gone); (c) a
+    tensor larger than a chunk (the f32 catconv panel of the largest subnet, 9.4 MB) gets a chunk of its own."""
+    from concurrent.futures import ThreadPoolExecutor
+    from sugar_amd.sweep import _prepare
+    dev = torch.device(DEV)
+    lens = synth.ragged_lengths(24, lo=24000, hi=40000, seed=21).tolist()
+    packed = sugar_amd.PackedUtterances(_Utts(synth.ragged_waveforms(lens, seed=21), [1] * 24), DEV, batch_size=8)
+    cfg_a, cfg_b = cfg_of(meta, "rand0"), cfg_of(meta, "largest")
+
+    def vectors_of(sub):
+        model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+        return sugar_amd.extract_vectors(model, packed).matrix.clone()
+
+    idle = _prepare(supernet, cfg_b, "bf16", dev)
+    want = vectors_of(idle)
+    torch.cuda.synchronize()
+    busy_model = _prepare(supernet, cfg_a, "bf16", dev)
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        for _ in range(3):
+            vectors_of(busy_model)                            # enqueued, not waited for
+        fut = pool.submit(_prepare, supernet, cfg_b, "bf16", dev)
+        for _ in range(3):
+            vectors_of(busy_model)
+        made_busy = fut.result()
+    assert torch.equal(vectors_of(made_busy), want)
+    torch.cuda.synchronize()
+    for sub in (idle, busy_model, made_busy):
+        sub.release()
+
+    f32 = _prepare(supernet, cfg_b, "fp32", dev)              # (c): parity of this path is test_*_fp32's; here it must load
+    assert torch.isfinite(vectors_of(f32)).all()
+    f32.release()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for i in range(24):
+        sub = _prepare(supernet, cfg_a if i % 2 else cfg_b, "bf16", dev)
+        sub.release()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info(dev)[0] - free0) < (64 << 20)
+
+
 def test_concurrent_streams_are_bit_identical(meta, supernet):
     """extract_vectors overlaps consecutive batches on HIP streams, which puts VALU-only kernels (the FFT front-end) and
     MFMA kernels on the same CU.  The vectors must be bit-identical to the one-stream result every time.  (With
