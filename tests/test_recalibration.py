@@ -106,15 +106,17 @@ def test_reset_bn_and_errors():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_conv_epilogue_statistics_equal_the_separate_pass(precision):
+@pytest.mark.parametrize("precision,wreg_min_r", [("fp32", None), ("bf16", None), ("bf16", 0)])
+def test_conv_epilogue_statistics_equal_the_separate_pass(precision, wreg_min_r):
     """The generic conv kernel's epilogue leaves the BatchNorm partial sums behind (ConvIO::stat_part); with
     recal_separate_stats=1 every BatchNorm runs bn_stats_kernel over the stored tensor instead.  Both sum the SAME stored
     values (f32 partials of 128 rows, then doubles, against doubles throughout), on a ragged batch whose last row tile is
     partial.  f32: every running statistic and the embeddings agree to f32 rounding.  bf16: the first BatchNorm fed by a
     fused conv (Res2 step 0 of block 0; layer1 and first_conv run on the LDS-DMA GEMMs in both modes) agrees to f32
     rounding; behind it a 1e-7 change of a scale moves bf16 roundings of the normalised tensor, so later layers are held
-    to the bf16 path's own noise level only."""
+    to the bf16 path's own noise level only.  gemm_wreg_min_r=0 sends layer1 and the 512-channel convs to the
+    weights-in-registers GEMM whatever the batch size, whose epilogue keeps its own running sums (the default threshold
+    is 19 200 frames; these 1 285 frames would stay on the tile kernels and their separate pass)."""
     dev = torch.device("cuda", 0)
     sup = sugar_amd.tdnn8m2g()
     sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
@@ -125,7 +127,10 @@ def test_conv_epilogue_statistics_equal_the_separate_pass(precision):
         sub = sup.clone(layout.BASE).set_precision(precision)
         spk = sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks()).to(dev)
         spk.train()
-        with sugar_amd._lib.tuned(recal_separate_stats=sep):
+        knobs = {"recal_separate_stats": sep}
+        if wreg_min_r is not None:
+            knobs["gemm_wreg_min_r"] = wreg_min_r
+        with sugar_amd._lib.tuned(**knobs):
             emb = spk.embed_ragged(wavs, normalize=False)
         spk.eval()
         out[sep] = (emb.cpu().numpy(), {k: v.clone() for k, v in sub.state_dict().items() if "running" in k})
