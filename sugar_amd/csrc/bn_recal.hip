@@ -227,7 +227,7 @@ int64_t bn_workspace_doubles(int c_max, int64_t R) {
 }
 
 int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, float momentum, double* d_part,
-                    float* d_scale, float* d_shift, int dtype, hipStream_t s, int part_blocks) {
+                    float* d_scale, float* d_shift, int dtype, hipStream_t s, int part_blocks, bool apply) {
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(C % E == 0 && C <= st.n && ld % E == 0 && ((uintptr_t)d_z & 15) == 0 && R > 0,
                   "bn_batch: bad shape C %d ld %d", C, ld);
@@ -249,6 +249,7 @@ int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, floa
     hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, s, d_part, nblk, C, (double)R,
                        st.gamma(), st.beta(), st.mean(), st.var(), momentum, d_scale, d_shift);
   SUGAR_LAUNCH_CHECK();
+  if (!apply) return SUGAR_OK;
   const int64_t items = R * (C / E);
   const unsigned blocks = (unsigned)(ceil_div(items, 256) < 4096 ? ceil_div(items, 256) : 4096);
   if (dtype == SUGAR_F32)

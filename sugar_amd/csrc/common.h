@@ -288,11 +288,14 @@ struct SELayer {            // device, f32, transposed for coalesced reads
 // scale[b][c] = sigmoid(W2 relu(W1 mean_t(y[b]) + b1) + b2)
 // d_part: se_part_floats floats, the per-(segment, channel slab) shares of the reduce layer (se_pool.hip)
 int64_t se_part_floats(const SELayer& se, int dtype, int B, int64_t R);
+// d_bn_scale / d_bn_shift (recalibration): y is read BEFORE its train-mode BatchNorm, whose affine of this batch they are
 int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, int t_max,
-                    float* d_part, float* d_scale, int dtype, hipStream_t s);
+                    float* d_part, float* d_scale, int dtype, hipStream_t s, const float* d_bn_scale = nullptr,
+                    const float* d_bn_shift = nullptr);
 // out = y * scale[b] + S ;  S += out (when write_S)                                    dynamictdnn.py:98-100, :657-660
 int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, void* d_S, int ldS, void* d_out,
-                    int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s);
+                    int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s,
+                    const float* d_bn_scale = nullptr, const float* d_bn_shift = nullptr);
 
 struct PoolLayer {
   void* w2 = nullptr;       // [ccat_pad32][bott] dtype : pooling.linear2.weight rows padded to a multiple of 32
@@ -333,7 +336,8 @@ int64_t bn_workspace_doubles(int c_max, int64_t R);
 // part_blocks > 0: d_part already holds that many row blocks of partials (written by the conv that produced z,
 // ConvIO::stat_part) and the statistics pass over z is skipped.
 int launch_bn_batch(void* d_z, int ld, int64_t R, int C, const BNState& st, float momentum, double* d_part,
-                    float* d_scale, float* d_shift, int dtype, hipStream_t s, int part_blocks = 0);
+                    float* d_scale, float* d_shift, int dtype, hipStream_t s, int part_blocks = 0, bool apply = true);
+// (apply = false: statistics, running update and this batch's (scale, shift) only; the consumer applies the affine)
 // x [B][ld] f32 <- train-mode BN over the B rows, in place (st.n channels)
 int launch_bn_rows(float* d_x, int ld, int B, const BNState& st, float momentum, hipStream_t s);
 // (scale, shift) of eval-mode BN from the running statistics

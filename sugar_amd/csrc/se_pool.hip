@@ -66,9 +66,14 @@ constexpr int SE_SEG = 2048;
 
 __device__ __forceinline__ int se_slot(const int32_t* row_off, int b) { return row_off[b] / SE_SEG + b; }
 
-template <typename T>
+// BNIN (BN recalibration): y is the conv's output BEFORE its train-mode BatchNorm, whose (scale, shift) of this batch
+// are bsc / bsh; the mean is linear, so mean(BN(y)) = scale mean(y) + shift and the BatchNorm needs no pass over y of
+// its own (se_apply_kernel<.., BNIN> applies it to the rows it reads anyway).
+template <typename T, bool BNIN = false>
 __global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, int ldy, const int32_t* __restrict__ row_off,
-                                                      SELayer se, int nslab, float* __restrict__ hpart) {
+                                                      SELayer se, int nslab, float* __restrict__ hpart,
+                                                      const float* __restrict__ bsc = nullptr,
+                                                      const float* __restrict__ bsh = nullptr) {
   constexpr int E = Chunk<T>::N, SC = 8 * E;          // channels per slab
   __shared__ float partial[32][SC + 1];
   __shared__ float msum[SC];
@@ -112,7 +117,12 @@ __global__ __launch_bounds__(256) void se_mean_kernel(const T* __restrict__ y, i
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) t += partial[k][tid];
-    msum[tid] = t / (float)n_utt;                      // this segment's share of the utterance mean
+    float share = t / (float)n_utt;                    // this segment's share of the utterance mean
+    if (BNIN) {
+      const int c = min(cbase + tid, c_p - 1);
+      share = cbase + tid < c_p ? fmaf(bsc[c], share, bsh[c] * ((float)n / (float)n_utt)) : 0.f;
+    }
+    msum[tid] = share;
   }
   __syncthreads();
   // this slab's share of reduce.weight x mean: thread (j, half) walks SC / 2 channels; weight rows of padded channels are 0
@@ -236,11 +246,13 @@ constexpr int APPLY_ROWS = 4;     // 256 chunks = one per thread (bf16): 32 rows
 #define SE_NT 1
 #endif
 
-template <typename T, bool NT_OUT = false>
+template <typename T, bool NT_OUT = false, bool BNIN = false>
 __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ y, int ldy,
                                                        const float* __restrict__ scale, int c_p, T* __restrict__ S,
                                                        int ldS, T* __restrict__ out, int ldo, int write_S,
-                                                       const int32_t* __restrict__ row_off) {
+                                                       const int32_t* __restrict__ row_off,
+                                                       const float* __restrict__ bsc = nullptr,
+                                                       const float* __restrict__ bsh = nullptr) {
   constexpr int E = Chunk<T>::N;
   const int b = blockIdx.y;
   const int s = row_off[b], n = row_off[b + 1] - s;
@@ -255,6 +267,10 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ y, 
     float vy[E], vs[E], vo[E];
     Chunk<T>::load(y + row * ldy + ch * E, vy);
     Chunk<T>::load(S + row * ldS + ch * E, vs);
+    if (BNIN) {                                        // y arrives before its train-mode BatchNorm (see se_mean_kernel)
+#pragma unroll
+      for (int i = 0; i < E; ++i) vy[i] = fmaf(vy[i], bsc[ch * E + i], bsh[ch * E + i]);
+    }
 #pragma unroll
     for (int i = 0; i < E; ++i) vo[i] = fmaf(vy[i], sc[ch * E + i], vs[i]);
     // the reference adds in f32; the running sum re-reads the *stored* (rounded) block output, as the next
@@ -371,14 +387,22 @@ int64_t se_part_floats(const SELayer& se, int dtype, int B, int64_t R) {
 // against 81 us for the three kernels -- with one workgroup per CU and equal-length utterances every CU idles through the
 // MLP's L2 round trips at the same time.
 int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* d_row_off, int B, int t_max,
-                           float* d_part, float* d_scale, int dtype, hipStream_t s) {
+                           float* d_part, float* d_scale, int dtype, hipStream_t s, const float* d_bn_scale,
+                           const float* d_bn_shift) {
   SUGAR_CHECK_ARG(t_max > 0 && d_part, "se: partial table missing");
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(se.c_p % E == 0 && se.c_p > 0, "se: channels %d unsupported", se.c_p);
   SUGAR_CHECK_ARG(se.hid > 0 && se.hid <= 1024 && ldy % E == 0, "se: bad hidden %d / ld %d", se.hid, ldy);
   const int nslab = se_slabs(se, dtype);
   const dim3 grid((unsigned)nslab, (unsigned)B, (unsigned)ceil_div(t_max, SE_SEG));
-  if (dtype == SUGAR_F32)
+  if (d_bn_scale) {                                    // recalibration: the BatchNorm of y folded in
+    if (dtype == SUGAR_F32)
+      hipLaunchKernelGGL((se_mean_kernel<float, true>), grid, dim3(256), 0, s, (const float*)d_y, ldy, d_row_off, se, nslab,
+                         d_part, d_bn_scale, d_bn_shift);
+    else
+      hipLaunchKernelGGL((se_mean_kernel<bf16, true>), grid, dim3(256), 0, s, (const bf16*)d_y, ldy, d_row_off, se, nslab,
+                         d_part, d_bn_scale, d_bn_shift);
+  } else if (dtype == SUGAR_F32)
     hipLaunchKernelGGL(se_mean_kernel<float>, grid, dim3(256), 0, s, (const float*)d_y, ldy, d_row_off, se, nslab, d_part);
   else
     hipLaunchKernelGGL(se_mean_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)d_y, ldy, d_row_off, se, nslab, d_part);
@@ -392,11 +416,19 @@ int launch_se_scale(const SELayer& se, const void* d_y, int ldy, const int32_t* 
 
 // out = y * scale[b] + S ;  S += out (when write_S)
 int launch_se_apply(const void* d_y, int ldy, const float* d_scale, int c_p, void* d_S, int ldS, void* d_out,
-                           int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s) {
+                           int ldo, int write_S, const int32_t* d_row_off, int B, int t_max, int dtype, hipStream_t s,
+                           const float* d_bn_scale, const float* d_bn_shift) {
   const int E = dtype == SUGAR_F32 ? 4 : 8;
   SUGAR_CHECK_ARG(c_p % E == 0 && ldy % E == 0 && ldS % E == 0 && ldo % E == 0, "se_apply: unaligned channels");
   const dim3 grid((unsigned)ceil_div(t_max, APPLY_ROWS), (unsigned)B);
-  if (dtype == SUGAR_F32)
+  if (d_bn_scale) {                                    // recalibration: the BatchNorm of y folded in
+    if (dtype == SUGAR_F32)
+      hipLaunchKernelGGL((se_apply_kernel<float, false, true>), grid, dim3(256), 0, s, (const float*)d_y, ldy, d_scale, c_p,
+                         (float*)d_S, ldS, (float*)d_out, ldo, write_S, d_row_off, d_bn_scale, d_bn_shift);
+    else
+      hipLaunchKernelGGL((se_apply_kernel<bf16, false, true>), grid, dim3(256), 0, s, (const bf16*)d_y, ldy, d_scale, c_p,
+                         (bf16*)d_S, ldS, (bf16*)d_out, ldo, write_S, d_row_off, d_bn_scale, d_bn_shift);
+  } else if (dtype == SUGAR_F32)
     hipLaunchKernelGGL(se_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)d_y, ldy, d_scale, c_p,
                        (float*)d_S, ldS, (float*)d_out, ldo, write_S, d_row_off);
   else if (SE_NT && write_S)

@@ -508,11 +508,11 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
   const bool fuse_stats = !tune_get(TUNE_RECAL_SEPARATE_STATS);
   const int cbn = n->c0p > n->midp_max ? n->c0p : n->midp_max;
   const int64_t stat_cap = bn_workspace_doubles(cbn, R);
-  auto conv_bn = [&](const ConvLayer& L, ConvIO io, int C, const BNState& st) {
+  auto conv_bn = [&](const ConvLayer& L, ConvIO io, int C, const BNState& st, bool apply = true) {
     int blocks = 0;
     if (fuse_stats) { io.stat_part = w.bnpart; io.stat_c = C; io.stat_cap = stat_cap; }
     if (int rc2 = launch_conv(raw_conv(L), io, w.rowseg, R, dt, s, &blocks)) return rc2;
-    return launch_bn_batch(io.y, io.ldy, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s, blocks);
+    return launch_bn_batch(io.y, io.ldy, R, C, st, momentum, w.bnpart, w.bnscale, w.bnshift, dt, s, blocks, apply);
   };
   if ((rc = launch_build_rowseg(row_off, B, t_max, w.rowseg, s))) return rc;
 
@@ -554,11 +554,17 @@ static int tdnn_recalibrate(SugarSubnet* n, const void* feats, const int32_t* ro
                                (size_t)b.wp * esz, (size_t)R, hipMemcpyDeviceToDevice, s));
     ConvIO l;
     l.x = w.mid2; l.ldx = b.midp; l.y = w.ybuf; l.ldy = n->c0p;
-    if ((rc = conv_bn(b.last, l, n->c0p, b.bn_last))) return rc;
-    if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.separt, w.sescale, dt, s))) return rc;
+    // last_conv's BatchNorm is not applied in a pass of its own: its consumers are the SE mean (linear: the affine goes
+    // on the mean) and se_apply (which reads every row anyway); w.bnscale / w.bnshift hold this batch's affine until
+    // the next BatchNorm's finalize, i.e. past both
+    const bool fold = fuse_stats;
+    if ((rc = conv_bn(b.last, l, n->c0p, b.bn_last, !fold))) return rc;
+    const float* bsc = fold ? w.bnscale : nullptr;
+    const float* bsh = fold ? w.bnshift : nullptr;
+    if ((rc = launch_se_scale(b.se, w.ybuf, n->c0p, row_off, B, t_max, w.separt, w.sescale, dt, s, bsc, bsh))) return rc;
     void* out = col(w.cat, (int64_t)i * n->c0p);
     if ((rc = launch_se_apply(w.ybuf, n->c0p, w.sescale, n->c0p, w.S, n->c0p, out, ldcat, i + 1 < n->depth, row_off, B,
-                              t_max, dt, s)))
+                              t_max, dt, s, bsc, bsh)))
       return rc;
   }
   ConvIO c;
