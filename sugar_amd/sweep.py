@@ -30,7 +30,7 @@ from .metrics import calculate_eer, calculate_mindcf
 from .models import SpeakerModel, WrappedModel, batch_forward
 from .scores import score_trials_device
 from .transforms import LogMelFbanks
-from .vectors import PackedUtterances, extract_vectors, shard_indices
+from .vectors import AUTO_BATCH, PackedUtterances, extract_vectors, shard_indices
 
 
 def config_key(config):
@@ -146,7 +146,8 @@ def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transfor
     mine = [configs[i] for i in shard_configs(supernet, configs, rank, world)]
     fb = transform if transform is not None else LogMelFbanks()
     # the evaluation list is walked and staged on the GPU once for all subnets
-    packed = PackedUtterances(veri_loader.dataset.utterances, dev, batch_size=max(1, int(veri_loader.batch_size)))
+    bs = int(veri_loader.batch_size)                   # (1 = the reference's whole-utterance mode: the packer chooses)
+    packed = PackedUtterances(veri_loader.dataset.utterances, dev, batch_size=bs if bs > 1 else AUTO_BATCH)
     veri_loader = _LoaderView(veri_loader, _TrialSnapshot(veri_loader.dataset))     # trial list parsed once
     results = {}
     # subnets cloned + packed ahead on host threads: True = 2 (one ahead left the launching thread waiting 6 ms per subnet

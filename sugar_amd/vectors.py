@@ -38,6 +38,7 @@ def plan_batches(lengths, batch_size, max_frames):
     return batches
 
 
+AUTO_BATCH = 256  # utterances per packed call when the caller passes the reference's batch_size = 1 (see extract_vectors)
 N_LANES = 2      # concurrent HIP streams of extract_vectors
 _LANES = {}      # device index -> the streams, created once (a subnet keeps one workspace per (device, stream))
 
@@ -347,6 +348,11 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
     model   : WrappedModel / SpeakerModel from sugar_amd.models
     datalst : an indexable dataset of {"file": str, "input": Tensor[n_seg, L] or [L]} (sugar/database.py:136-142),
               or a PackedUtterances built from one (then `device`, `batch_size`, `max_frames` are the packing's)
+    batch_size : utterances per packed call, at most (and at most `max_frames` frames).  1 -- the reference's default and
+              its only choice for whole utterances of different lengths, which it then runs ONE AT A TIME
+              (sugar/vectors.py:98-124) -- means "whole utterances" here as well, not "one per call": ragged utterances
+              pack into one call without padding, so the packer takes up to AUTO_BATCH (256) of them.  An utterance's
+              vector does not depend on what it is batched with beyond the rounding of the compute dtype.
     n_jobs  : host threads that pack the next batch into pinned staging memory while the GPU computes (the reference's
               joblib threads / DataLoader workers, sugar/vectors.py:117-121, 130-133); only used for host-resident lists
     rank, world_size, shard : multi-GPU extraction of ONE model's vectors (BASELINE config 4) -- opt-in, never
@@ -361,6 +367,7 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
     Returns a VectorTable: {file: Tensor[n_seg, 192]} on the device.
     """
     rank, world = _dist_info(rank, world_size, shard)
+    batch_size = AUTO_BATCH if int(batch_size) <= 1 else int(batch_size)
     if world > 1:
         return _extract_sharded(model, datalst, norm, device, n_jobs, batch_size, max_frames, rank, world)
     packed = datalst if isinstance(datalst, PackedUtterances) else None

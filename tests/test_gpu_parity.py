@@ -180,8 +180,16 @@ def test_extract_vectors_and_score_trials_ordering(supernet):
         v = vectors["utt%04d.wav" % i]
         assert v.shape == (segs[i], 192)
         assert (v.norm(dim=1) - 1).abs().max() < 1e-5
-    # batch composition must not matter
-    v1 = sugar_amd.extract_vectors(model, data, norm=True, device=DEV, batch_size=1)
+    # batch composition must not matter.  batch_size=1 is the reference's whole-utterance mode (it runs those one at a
+    # time); here the packer then chooses, and everything of this list goes out in ONE call
+    calls = []
+    orig = sugar_amd.SpeakerModel._embed_flat
+    sugar_amd.SpeakerModel._embed_flat = lambda self, sub, flat, plan, nrm: (calls.append(plan.B), orig(self, sub, flat, plan, nrm))[1]
+    try:
+        v1 = sugar_amd.extract_vectors(model, data, norm=True, device=DEV, batch_size=1)
+    finally:
+        sugar_amd.SpeakerModel._embed_flat = orig
+    assert calls == [sum(segs)]
     for k in vectors:
         assert (v1[k] - vectors[k]).abs().max() < 2e-2
     lab, a, b = synth.trial_pairs(n_utts, 400, seed=3)
