@@ -213,6 +213,23 @@ int sugar_conv1d_fwd(const float* h_w, const SugarBN* h_bn, int cout, int cin, i
  * back, copied by n_threads threads over equal byte ranges.  No GPU call; the caller then issues ONE host-to-device copy. */
 int sugar_pack_segments(const float* const* h_src, const int64_t* h_len, int n, float* h_dst, int n_threads);
 
+/* HOST memory and files only.  Replace, for evaluation lists of mono 16-bit PCM wav files: the per-item Python loader
+ * loadWAV (sugar/waveforms.py:47-115: scipy wavfile.read -> np.pad(mode="wrap") -> whole utterance or np.linspace crops
+ * -> float32) as run by the reference's DataLoader workers / joblib threads (sugar/vectors.py:117-121, 130-133),
+ * followed by Utterance.collate_fn's torch.cat (sugar/database.py:144-158).
+ *   sugar_wav_probe: walks the RIFF chunks of h_paths[0 .. n): h_n_samples[i] = samples of file i and h_data_off[i] = byte
+ *     offset of its data when it is mono, 16-bit PCM at `sample_rate`; h_n_samples[i] = -1 for any other format (the
+ *     caller keeps the Python loader for such a list).  SUGAR_EINVAL when a file cannot be read.
+ *   sugar_wav_load: segment j = h_seg_len[j] samples of file h_seg_file[j] from sample h_seg_start[j] on, continued
+ *     periodically past the file's end (what the wrap padding appends), converted to float32 (exact) and written to
+ *     h_dst (typically pinned) one segment after the other, by n_threads threads over equal sample ranges using pread.
+ * Which segments a file yields (padding floor, crop starts) stays on the Python side (sugar_amd/waveforms.py). */
+int sugar_wav_probe(const char* const* h_paths, int n, int sample_rate, int64_t* h_n_samples, int64_t* h_data_off,
+                    int n_threads);
+int sugar_wav_load(const char* const* h_paths, const int64_t* h_n_samples, const int64_t* h_data_off,
+                   const int32_t* h_seg_file, const int64_t* h_seg_start, const int64_t* h_seg_len, int n_segs,
+                   float* h_dst, int n_threads);
+
 /* Replaces: F.normalize(vec, p=2, dim=1) (sugar/vectors.py:108-109,143-144), in place, float32 [n][dim]. */
 int sugar_l2norm(float* d_x, int64_t n, int dim, void* stream);
 

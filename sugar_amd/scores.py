@@ -105,11 +105,13 @@ def _trial_index(trials, keys, dev):
     """(labels ndarray, [[enroll, test], ...], enroll row index, test row index on `dev`) of a trial list against the
     utterance order `keys`.  A sweep scores the same list once per subnet, so the result is remembered -- only on
     VerificationTrials-shaped objects (`labels` / `enrolls` / `tests` lists filled once by load_trial), keyed by the
-    file list's identity, the device and a sampled content fingerprint; plain lists are indexed every time."""
+    file list (the same object, or an equal one: every extract_vectors call over a file list builds a new list of the
+    same names, and re-indexing 37 720 trials is 60 ms of interpreter time), the device and a sampled content
+    fingerprint; plain lists are indexed every time."""
     memo_ok = all(isinstance(getattr(trials, a, None), list) for a in ("labels", "enrolls", "tests"))
     fp = _fingerprint(trials) if memo_ok else None
     memo = getattr(trials, "_sugar_trial_index", None) if memo_ok else None
-    if memo is not None and memo[0] is keys and memo[1] == fp and memo[2] == dev:
+    if memo is not None and (memo[0] is keys or memo[0] == keys) and memo[1] == fp and memo[2] == dev:
         return memo[3]
     index = {k: i for i, k in enumerate(keys)}
     labels, pairs, e_idx, t_idx = [], [], [], []

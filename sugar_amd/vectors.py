@@ -7,6 +7,8 @@ a DataLoader (:126-153).  Here both become packed batches: utterances are sorted
 bounded by ``batch_size`` utterances and ``max_frames`` frames, each batch is ONE fused C-ABI call
 (fbank + TDNN + L2 norm) with no padding, and results are scattered back to the reference's per-file layout.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -162,130 +164,288 @@ class PackedUtterances:
     dataset (4 874 __getitem__ calls, ~45 ms) once instead of per subnet.
     """
 
-    def __init__(self, datalst, device="cuda:0", batch_size=256, max_frames=262144):
+    def __init__(self, datalst, device="cuda:0", batch_size=256, max_frames=262144, n_jobs=8):
         from .transforms import BatchPlan
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.SugarError("sugar_amd runs on an MI355X only: pass device='cuda:N' (there is no CPU fallback)")
+        self.table_index = None                        # VectorTable.index of the first table built over this list
+        self.batches = []
+        n = len(datalst)
+        first = _segments(datalst[0])[0] if n else None
+        if first is not None and not first.is_cuda:
+            # a host list (files, or tensors in host memory): streamed through the pinned staging of _HostFeed -- items
+            # read ahead by n_jobs threads, one native pack + ONE copy per batch -- and kept here batch by batch
+            feed = _HostFeed(self.device, datalst, n_jobs, batch_size, max_frames)
+            main = torch.cuda.current_stream(self.device)
+            try:
+                for k, slot, total, plan, rows in feed:
+                    main.wait_event(feed.h2d_done[slot])
+                    self.batches.append((rows, feed.dev[slot][:total].clone(), plan))
+                    feed.done(slot, main)
+            finally:
+                feed.close()
+            main.synchronize()                         # (rows / plans were allocated on the producer's thread: see extract_vectors)
+            self.files, self.counts, self.n_rows = feed.files, feed.counts, feed.n_rows
+            return
         files, counts, segs = [], [], []
-        for idx in range(len(datalst)):
+        for idx in range(n):
             item = datalst[idx]
             files.append(item["file"])
             ss = _segments(item)
             counts.append(len(ss))
             segs.extend(ss)
         self.files, self.counts, self.n_rows = files, counts, len(segs)
-        self.table_index = None                        # VectorTable.index of the first table built over this list
         lengths = [int(s.numel()) for s in segs]
-        self.batches = []
-        host = bool(segs) and all((not s.is_cuda) and s.dtype == torch.float32 and s.is_contiguous() for s in segs)
-        batches = list(plan_batches(lengths, max(1, batch_size), max_frames))
-        if host:         # one native pack into pinned memory + ONE copy per batch instead of one pageable copy per segment
-            import ctypes
-            cap = max(sum(lengths[i] for i in b) for b in batches)
-            pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(min(2, len(batches)))]
-            copied = [None] * len(pins)                # the event after the last copy out of each staging buffer
-        for k, batch in enumerate(batches):
-            if host:
-                n, total = len(batch), sum(lengths[i] for i in batch)
-                pin = pins[k % len(pins)]
-                if copied[k % len(pins)] is not None:
-                    copied[k % len(pins)].synchronize()
-                src = (ctypes.c_void_p * n)(*[segs[i].data_ptr() for i in batch])
-                lens = (ctypes.c_int64 * n)(*[lengths[i] for i in batch])
-                _lib.check(_lib.lib().sugar_pack_segments(src, lens, n, pin.data_ptr(), 8), "sugar_pack_segments")
-                flat = torch.empty(total, dtype=torch.float32, device=self.device)
-                flat.copy_(pin[:total], non_blocking=True)
-                copied[k % len(pins)] = torch.cuda.Event()
-                copied[k % len(pins)].record()
-            else:
-                flat = torch.cat([segs[i].reshape(-1).to(self.device, non_blocking=True).float() for i in batch])
+        for batch in plan_batches(lengths, max(1, batch_size), max_frames):
+            flat = torch.cat([segs[i].reshape(-1).to(self.device, non_blocking=True).float() for i in batch])
             self.batches.append((torch.tensor(batch, device=self.device), flat, BatchPlan([lengths[i] for i in batch],
                                                                                           self.device)))
-        if host:
-            torch.cuda.current_stream(self.device).synchronize()
 
     def __len__(self):
         return len(self.files)
 
 
+def _walk(datalst, n_jobs):
+    """datalst[0], datalst[1], ... in order, loaded by `n_jobs` threads running ahead of the consumer (the reference's
+    DataLoader workers / joblib threads, sugar/vectors.py:117-121, 130-133): reading and decoding a wav file releases the
+    interpreter lock, and a serial walk over 4 874 files costs far more than embedding them.  The first items are
+    loaded in line and timed: a list that is already in memory (items in tens of microseconds) is walked serially --
+    a future per item costs more than such an item and the loader threads only fight the launching thread for the
+    interpreter lock (4 874 in-memory items: 0.10 s serial, 0.26 s through the pool)."""
+    import time
+    n = len(datalst)
+    probe = min(n, 8)
+    t0 = time.perf_counter()
+    for idx in range(probe):
+        yield datalst[idx]          # (the consumer's time between two items is counted as well: an upper bound)
+    if probe == n:
+        return
+    per_item = (time.perf_counter() - t0) / probe
+    if n_jobs <= 1 or per_item < 2e-4:
+        for idx in range(probe, n):
+            yield datalst[idx]
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    per_task = 4                    # items per future: amortises the pool's hand-over
+    with ThreadPoolExecutor(max_workers=n_jobs, thread_name_prefix="sugar-load") as pool:
+        window, nxt = deque(), probe
+        while nxt < n or window:
+            while nxt < n and len(window) < 4 * n_jobs:
+                hi = min(n, nxt + per_task)
+                window.append(pool.submit(lambda a, b: [datalst[i] for i in range(a, b)], nxt, hi))
+                nxt = hi
+            for item in window.popleft().result():
+                yield item
+
+
 class _HostFeed:
     """
-    Host-fed batches for extract_vectors' list path (the reference feeds its forward from DataLoader workers,
-    sugar/vectors.py:126-153): a producer thread packs batch k + 1 into a PINNED staging buffer (ONE native call,
-    sugar_pack_segments: `workers` threads over equal byte ranges, no interpreter lock) and sends it over PCIe on a
-    copy stream while the GPU computes batch k.  Three slots (pinned buffer + device buffer + two events each), so packing, the PCIe copy and the
-    compute of three consecutive batches overlap; a slot is reused once the forward that read it has finished.
-    Without this the list path issued one synchronous pageable-memory copy per segment (4 874 of them for BASELINE
-    config 4) from the thread that also launches the kernels.
+    Host-fed batches for extract_vectors' list path and for PackedUtterances (the reference feeds its forward from
+    DataLoader workers, sugar/vectors.py:126-153).  ONE producer thread streams the list: `workers` loader threads read
+    items ahead in order (_walk); every CHUNK_FRAMES frames of loaded audio are sorted by length and cut into batches
+    (<= batch_size utterances, <= max_frames frames); each batch is packed into a PINNED staging buffer with one
+    native call (sugar_pack_segments: `workers` threads over equal byte ranges, no interpreter lock) and sent over PCIe
+    on a copy stream while the GPU computes the batch before.  Three slots (pinned buffer + device buffer + two events
+    each), so packing, the PCIe copy and the compute of three consecutive batches overlap; a slot is reused once the
+    forward that read it has finished.  The list is never held whole: host memory is bounded by a chunk plus the slots
+    whatever its length (Vox1-E / -H are 145 k / 138 k utterances), and the GPU starts on the first chunk while the
+    rest is still being read.  Without this the list path walked the whole list first, serially, and then issued one
+    synchronous pageable-memory copy per segment from the thread that also launches the kernels.
+
+    Iterating yields (k, slot, n_samples, plan, rows): batch k sits in self.dev[slot][:n_samples] once
+    self.h2d_done[slot] has fired; rows = the rows of the result matrix its utterances own (int64 on the device, list
+    order).  After the iteration: self.files, self.counts, self.n_rows.
     """
     SLOTS = 3
+    CHUNK_FRAMES = 1 << 20        # ~2.9 hours of audio: four full batches to sort and cut at a time
 
-    def __init__(self, device, segs, lengths, batches, workers):
-        import ctypes
+    def __init__(self, device, datalst, workers, batch_size, max_frames):
         import queue
         import threading
-        import time
-        from .transforms import BatchPlan
         self.device = device
-        cap = max(sum(lengths[i] for i in b) for b in batches)
-        # (pin_memory=True: straight from torch's caching pinned allocator; `.pin_memory()` on a fresh tensor copies the
-        # whole buffer once more -- 0.5 GB of memcpy per call for three 168 MB slots, a third of config 4's wall-clock)
-        self.pinned = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(self.SLOTS)]
-        self.dev = [torch.empty(cap, dtype=torch.float32, device=device) for _ in range(self.SLOTS)]
+        self.workers = max(1, int(workers))
+        self.batch_size, self.max_frames = max(1, int(batch_size)), int(max_frames)
+        self.pinned = [None] * self.SLOTS
+        self.dev = [None] * self.SLOTS
         self.h2d_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.free = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.copy_stream = torch.cuda.Stream(device)
         self.q = queue.Queue()
         self.sem = threading.Semaphore(self.SLOTS)                # slots the consumer has handed back (see done())
-        self.workers = max(1, int(workers))
         self._stop = False
-        self.stats = {"pack_s": 0.0, "wait_slot_s": 0.0, "bytes": 0}   # host-side seconds of the producer (diagnostics)
-
-        def pack(dst, batch):
-            """All float32 contiguous segments of the batch in ONE native call (sugar_pack_segments: n_jobs threads over
-            equal byte ranges, no interpreter lock held); anything else falls back to tensor.copy_ per segment."""
-            if all(segs[i].dtype == torch.float32 and segs[i].is_contiguous() for i in batch):
-                n = len(batch)
-                src = (ctypes.c_void_p * n)(*[segs[i].data_ptr() for i in batch])
-                lens = (ctypes.c_int64 * n)(*[lengths[i] for i in batch])
-                _lib.check(_lib.lib().sugar_pack_segments(src, lens, n, dst.data_ptr(), self.workers), "sugar_pack_segments")
-                return
-            off = 0
-            for i in batch:
-                dst[off:off + lengths[i]].copy_(segs[i].reshape(-1))
-                off += lengths[i]
-
-        def produce():
-            try:
-                with torch.cuda.device(device):
-                    for k, batch in enumerate(batches):
-                        t0 = time.perf_counter()
-                        self.sem.acquire()                        # slot k % SLOTS: handed back by done() ...
-                        if self._stop:
-                            return
-                        s = k % self.SLOTS
-                        if k >= self.SLOTS:
-                            self.free[s].synchronize()            # ... and the forward that read it has finished
-                        t1 = time.perf_counter()
-                        off = sum(lengths[i] for i in batch)
-                        pack(self.pinned[s], batch)
-                        self.stats["wait_slot_s"] += t1 - t0
-                        self.stats["pack_s"] += time.perf_counter() - t1
-                        self.stats["bytes"] += 4 * off
-                        plan = BatchPlan([lengths[i] for i in batch], device)
-                        idx = torch.tensor(batch, dtype=torch.int64).to(device)
-                        with torch.cuda.stream(self.copy_stream):
-                            self.dev[s][:off].copy_(self.pinned[s][:off], non_blocking=True)
-                            self.h2d_done[s].record(self.copy_stream)
-                        self.q.put((k, s, off, plan, idx))
-                self.q.put(None)
-            except BaseException as e:                            # surfaces in the consumer
-                self.q.put(e)
-
-        self.thread = threading.Thread(target=produce, name="sugar-hostfeed", daemon=True)
+        self.files, self.counts, self.n_rows = [], [], 0
+        self.stats = {"load_s": 0.0, "pack_s": 0.0, "wait_slot_s": 0.0, "bytes": 0}   # producer-side seconds (diagnostics)
+        self.thread = threading.Thread(target=self._produce, args=(datalst,), name="sugar-hostfeed", daemon=True)
         self.thread.start()
 
+    # ---- producer thread -------------------------------------------------------------------------------------
+    def _slot(self, s, need):
+        """Staging buffers of slot s for `need` samples (grown when a batch -- one very long utterance -- exceeds them).
+        (pin_memory=True: straight from torch's caching pinned allocator; `.pin_memory()` on a fresh tensor copies the
+        whole buffer once more -- 0.5 GB of memcpy per call for three 168 MB slots.)"""
+        if self.pinned[s] is None or self.pinned[s].numel() < need:
+            cap = max(need, self.max_frames * 160)
+            self.pinned[s] = torch.empty(cap, dtype=torch.float32, pin_memory=True)
+            self.dev[s] = torch.empty(cap, dtype=torch.float32, device=self.device)
+
+    def _pack(self, dst, segs):
+        """All float32 contiguous host segments of the batch in ONE native call; anything else with tensor.copy_."""
+        import ctypes
+        if all((not t.is_cuda) and t.dtype == torch.float32 and t.is_contiguous() for t in segs):
+            n = len(segs)
+            src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in segs])
+            lens = (ctypes.c_int64 * n)(*[t.numel() for t in segs])
+            _lib.check(_lib.lib().sugar_pack_segments(src, lens, n, dst.data_ptr(), self.workers), "sugar_pack_segments")
+            return
+        off = 0
+        for t in segs:
+            dst[off:off + t.numel()].copy_(t.reshape(-1))
+            off += t.numel()
+
+    def _acquire(self, k):
+        """Slot of batch k once the consumer has handed it back and the forward that read it has run; None: stopped."""
+        import time
+        t0 = time.perf_counter()
+        self.sem.acquire()                                        # slot k % SLOTS: handed back by done() ...
+        if self._stop:
+            return None
+        s = k % self.SLOTS
+        if k >= self.SLOTS:
+            self.free[s].synchronize()                            # ... and the forward that read it has finished
+        self.stats["wait_slot_s"] += time.perf_counter() - t0
+        return s
+
+    def _emit(self, k, s, lengths, rows):
+        """Batch k is in self.pinned[s]: its index arrays, the copy to the device, the hand-over to the consumer."""
+        from .transforms import BatchPlan
+        total = sum(lengths)
+        self.stats["bytes"] += 4 * total
+        plan = BatchPlan(lengths, self.device)
+        idx = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        with torch.cuda.stream(self.copy_stream):
+            self.dev[s][:total].copy_(self.pinned[s][:total], non_blocking=True)
+            self.h2d_done[s].record(self.copy_stream)
+        self.q.put((k, s, total, plan, idx))
+
+    def _send(self, k, segs, rows):
+        import time
+        s = self._acquire(k)
+        if s is None:
+            return False
+        t1 = time.perf_counter()
+        lengths = [int(t.numel()) for t in segs]
+        self._slot(s, sum(lengths))
+        self._pack(self.pinned[s], segs)
+        self.stats["pack_s"] += time.perf_counter() - t1
+        self._emit(k, s, lengths, rows)
+        return True
+
+    def _native_list(self, datalst):
+        """An evaluation list of wav FILES (database.Utterance in eval mode, possibly a rank's _Subset of one) whose
+        files are all mono 16-bit PCM at 16 kHz: (paths, samples per file, data offsets, segment starts [n, n_seg],
+        segment lengths [n]) for the native reader (sugar_wav_probe / sugar_wav_load), else None -- any other dataset or
+        format goes through its own __getitem__."""
+        import ctypes
+        from .database import Utterance
+        from .waveforms import eval_segments
+        base, order = (datalst.data, datalst.indices) if isinstance(datalst, _Subset) else (datalst, None)
+        if type(base) is not Utterance or not base.mode_eval or base.ndim != 1 or len(datalst) == 0:
+            return None
+        paths = [base.path(i) for i in (order if order is not None else range(len(base)))]
+        n = len(paths)
+        arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        size = np.empty(n, dtype=np.int64)
+        off = np.empty(n, dtype=np.int64)
+        rc = _lib.lib().sugar_wav_probe(arr, n, 16000, size.ctypes.data, off.ctypes.data, self.workers)
+        if rc != 0 or (size < 0).any():
+            return None                                # (unreadable files raise from the Python loader, with its message)
+        starts, lengths = eval_segments(size, base.num_samples, base.num_eval)
+        return paths, arr, size, off, starts, lengths
+
+    def _produce_native(self, native):
+        import time
+        paths, arr, size, off, starts, lengths = native
+        n, n_seg = starts.shape
+        self.files, self.counts, self.n_rows = list(paths), [n_seg] * n, n * n_seg
+        seg_frames = 1 + lengths // 160                # num_frames of every segment of a file
+        k, lo = 0, 0
+        while lo < n:
+            hi, frames = lo, 0
+            while hi < n and frames < self.CHUNK_FRAMES:
+                frames += int(seg_frames[hi]) * n_seg
+                hi += 1
+            # the chunk's segments, file-major: segment j of file f is row f * n_seg + j of the result
+            f_idx = np.repeat(np.arange(lo, hi, dtype=np.int32), n_seg)
+            s_start = starts[lo:hi].reshape(-1)
+            s_len = np.repeat(lengths[lo:hi], n_seg)
+            rows = np.arange(lo * n_seg, hi * n_seg, dtype=np.int64)
+            for batch in plan_batches(s_len.tolist(), self.batch_size, self.max_frames):
+                s = self._acquire(k)
+                if s is None:
+                    return
+                t1 = time.perf_counter()
+                b = np.asarray(batch, dtype=np.int64)
+                bf, bs, bl = np.ascontiguousarray(f_idx[b]), np.ascontiguousarray(s_start[b]), np.ascontiguousarray(s_len[b])
+                self._slot(s, int(bl.sum()))
+                _lib.check(_lib.lib().sugar_wav_load(arr, size.ctypes.data, off.ctypes.data, bf.ctypes.data, bs.ctypes.data,
+                                                     bl.ctypes.data, len(batch), self.pinned[s].data_ptr(), self.workers),
+                           "sugar_wav_load")
+                self.stats["load_s"] += time.perf_counter() - t1
+                self._emit(k, s, bl.tolist(), rows[b].tolist())
+                k += 1
+            lo = hi
+
+    def _produce(self, datalst):
+        import time
+        try:
+            with torch.cuda.device(self.device):
+                native = self._native_list(datalst)
+                if native is not None:
+                    self.stats["native_reader"] = 1
+                    self._produce_native(native)
+                    if not self._stop:
+                        self.q.put(None)
+                    return
+                k, row, segs, rows, frames = 0, 0, [], [], 0
+
+                def flush():
+                    nonlocal k, segs, rows, frames
+                    lengths = [int(t.numel()) for t in segs]
+                    for batch in plan_batches(lengths, self.batch_size, self.max_frames):
+                        if not self._send(k, [segs[i] for i in batch], [rows[i] for i in batch]):
+                            return False
+                        k += 1
+                    segs, rows, frames = [], [], 0
+                    return True
+
+                t0 = time.perf_counter()
+                for item in _walk(datalst, self.workers):
+                    ss = _segments(item)
+                    self.files.append(item["file"])
+                    self.counts.append(len(ss))
+                    for t in ss:
+                        segs.append(t)
+                        rows.append(row)
+                        row += 1
+                        frames += num_frames(int(t.numel()))
+                    if frames >= self.CHUNK_FRAMES:
+                        self.stats["load_s"] += time.perf_counter() - t0
+                        if not flush():
+                            return
+                        t0 = time.perf_counter()
+                    if self._stop:
+                        return
+                self.stats["load_s"] += time.perf_counter() - t0
+                self.n_rows = row
+                if segs and not flush():
+                    return
+            self.q.put(None)
+        except BaseException as e:                                # surfaces in the consumer
+            self.q.put(e)
+
+    # ---- consumer --------------------------------------------------------------------------------------------
     def __iter__(self):
         while True:
             item = self.q.get()
@@ -391,6 +551,38 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
         for k, (idx, flat, plan) in enumerate(packed.batches):
             with torch.cuda.stream(lanes[k % len(lanes)]):
                 out[idx] = spk._embed_flat(sub, flat, plan, bool(norm))
+    elif len(datalst) and not _segments(datalst[0])[0].is_cuda:
+        # host-resident list (files, or tensors in host memory): streamed -- items read ahead by n_jobs threads, pinned
+        # triple-buffered staging on a copy stream, the GPU starts on the first chunk (_HostFeed)
+        from .transforms import LogMelFbanks
+        if not isinstance(getattr(spk, "__T__", None), LogMelFbanks):
+            raise _lib.SugarError("extract_vectors needs the fused LogMelFbanks + TDNN path")
+        sub = spk._subnet()
+        sub.eval_handle(device)                                   # pack the weights before the pipeline starts
+        feed = _HostFeed(device, datalst, max(1, int(n_jobs)), batch_size, max_frames)
+        # the batch plans and row indices are allocated by the producer thread (on ITS stream) and read by kernels
+        # on the lanes: they stay referenced until the lanes have been joined, or the caching allocator would hand
+        # their memory to the producer's next batch while a lane still has to read it
+        keep, embs = [], []
+        try:
+            for k, slot, total, plan, rows in feed:
+                lane = lanes[k % len(lanes)]
+                lane.wait_event(feed.h2d_done[slot])
+                with torch.cuda.stream(lane):
+                    emb = spk._embed_flat(sub, feed.dev[slot][:total], plan, bool(norm))
+                keep.append((plan, rows, emb))
+                embs.append((rows, emb))
+                feed.done(slot, lane)
+        finally:
+            feed.close()
+        extract_vectors.last_hostfeed_stats = dict(feed.stats)       # diagnostics (tools/hostfed_bench.py)
+        for lane in lanes:
+            lane.synchronize()
+        files, counts = feed.files, feed.counts
+        out = torch.empty(feed.n_rows, 192, dtype=torch.float32, device=device)
+        if embs:
+            out[torch.cat([r for r, _ in embs])] = torch.cat([e for _, e in embs])
+        del keep, embs
     else:
         files, counts, segs = [], [], []
         for idx in range(len(datalst)):
@@ -401,39 +593,11 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
             segs.extend(ss)
         lengths = [int(s.numel()) for s in segs]
         out = torch.empty(len(segs), 192, dtype=torch.float32, device=device)
-        batches = plan_batches(lengths, max(1, batch_size), max_frames)
-        if segs and not any(s.is_cuda for s in segs):
-            # host-resident list: pinned, triple-buffered staging on a copy stream, packed by n_jobs host threads
-            from .transforms import LogMelFbanks
-            if not isinstance(getattr(spk, "__T__", None), LogMelFbanks):
-                raise _lib.SugarError("extract_vectors needs the fused LogMelFbanks + TDNN path")
-            sub = spk._subnet()
-            sub.eval_handle(device)                               # pack the weights before the pipeline starts
-            feed = _HostFeed(device, segs, lengths, batches, max(1, int(n_jobs)))
-            # the batch plans and row indices are allocated by the producer thread (on ITS stream) and read by kernels
-            # on the lanes: they stay referenced until the lanes have been joined, or the caching allocator would hand
-            # their memory to the producer's next batch while a lane still has to read it
-            keep = []
-            try:
-                for k, slot, total, plan, idx in feed:
-                    keep.append((plan, idx))
-                    lane = lanes[k % len(lanes)]
-                    lane.wait_event(feed.h2d_done[slot])
-                    with torch.cuda.stream(lane):
-                        out[idx] = spk._embed_flat(sub, feed.dev[slot][:total], plan, bool(norm))
-                    feed.done(slot, lane)
-            finally:
-                feed.close()
-            extract_vectors.last_hostfeed_stats = dict(feed.stats)   # diagnostics (tools/hostfed_bench.py)
-            for lane in lanes:
-                lane.synchronize()
-            del keep
-        else:
-            for k, batch in enumerate(batches):
-                with torch.cuda.stream(lanes[k % len(lanes)]):
-                    wavs = [segs[i].to(device, non_blocking=True) for i in batch]
-                    emb = spk.embed_ragged(wavs, normalize=bool(norm))
-                    out[torch.tensor(batch, device=device)] = emb
+        for k, batch in enumerate(plan_batches(lengths, max(1, batch_size), max_frames)):
+            with torch.cuda.stream(lanes[k % len(lanes)]):
+                wavs = [segs[i].to(device, non_blocking=True) for i in batch]
+                emb = spk.embed_ragged(wavs, normalize=bool(norm))
+                out[torch.tensor(batch, device=device)] = emb
     for lane in lanes:
         main.wait_stream(lane)
     if packed is None:

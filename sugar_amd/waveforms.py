@@ -53,6 +53,24 @@ def loadWAV(path, num_samples=48000, mode_eval=False, num_eval=6, sample_rate=16
     return wave.astype(np.float32)
 
 
+def eval_segments(audiosize, num_samples=48000, num_eval=6, min_samples=48000):
+    """
+    The segments loadWAV(mode_eval=True) cuts from files of `audiosize` samples (int array), WITHOUT reading them:
+    (starts [n_files, n_seg], length) in samples of the wrap-padded waveform -- sample i of the padded waveform is
+    sample i mod audiosize of the file (np.pad mode="wrap").  num_samples == 0: one segment per file, the whole padded
+    utterance (lengths differ per file: returned as an array).  Same arithmetic as loadWAV above (np.linspace on the
+    padded size, int() truncation), so a native reader that follows this plan returns loadWAV's samples exactly.
+    """
+    assert not (min_samples is None and num_samples == 0), "Given min is None with 0 samples"
+    size = np.asarray(audiosize, dtype=np.int64)
+    floor = min_samples if min_samples is not None and min_samples >= num_samples else num_samples
+    padded = np.where(size <= floor, floor + 1, size)
+    if num_samples == 0:
+        return np.zeros((size.shape[0], 1), dtype=np.int64), padded
+    starts = np.linspace(0, padded - num_samples, num=num_eval, axis=-1)      # per file: linspace(0, len - num_samples, num_eval)
+    return starts.astype(np.int64), np.full(size.shape[0], num_samples, dtype=np.int64)
+
+
 def wav_segment(audio, num_samples=48000, noverlap=None):
     """
     sugar/waveforms.py:118-146: wrap-pad the waveform by num_samples - len % num_samples (a whole extra segment when the

@@ -96,3 +96,36 @@ def test_veri_validate_from_files(tmp_path):
     want = [torch.nn.functional.cosine_similarity(v3[e].unsqueeze(-1), v3[t].unsqueeze(-1).transpose(0, 2)).mean().item()
             for e, t in pairs]
     assert np.abs(s3 - np.array(want)).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_native_file_feed_equals_python_loader(tmp_path):
+    """An Utterance list of 16-bit PCM files goes through the host feed's native reader (sugar_wav_probe / sugar_wav_load:
+    no per-item Python); any other dataset -- here a subclass with the same items -- through its own __getitem__, on loader
+    threads.  Same files, same batches: the vectors are bit-equal, for whole utterances and for crops, with one packing
+    thread and with several, and the feed says which reader it used."""
+    root = str(tmp_path)
+    write_files(root)
+
+    class PyUtterance(Utterance):        # same items, but not the class the native reader recognises
+        pass
+
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    sub = sup.clone(layout.SMALLEST).set_precision("bf16")
+    model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).cuda().eval()
+    for num_samples, num_eval in ((0, 1), (16000, 3)):
+        tr = VerificationTrials(os.path.join(root, "trials.txt"), num_samples=num_samples, mode_eval=True,
+                                num_eval=num_eval, trials_dir=root)
+        u = tr.utterances
+        py = PyUtterance(u.datalst, u.num_samples, u.mode_eval, u.num_eval, u.root_dir)
+        got = {}
+        for name, data, jobs in (("native", u, 1), ("native4", u, 4), ("python", py, 1), ("python4", py, 4)):
+            v = sugar_amd.extract_vectors(model, data, device="cuda:0", n_jobs=jobs, batch_size=3)
+            assert bool(sugar_amd.extract_vectors.last_hostfeed_stats.get("native_reader")) == name.startswith("native")
+            assert list(v.keys()) == [u.path(i) for i in range(len(u))]
+            got[name] = v.matrix.clone()
+        for name in ("native4", "python", "python4"):
+            assert torch.equal(got[name], got["native"]), (num_samples, name)
+        staged = sugar_amd.extract_vectors(model, u.stage("cuda:0", batch_size=3))
+        assert torch.equal(staged.matrix, got["native"])

@@ -223,3 +223,64 @@ def test_vector_table_is_a_lazy_dict_with_dict_semantics():
     assert type(p) is dict and torch.equal(p["b"], ref["b"])
     e = VectorTable([], [], torch.empty(0, 4))
     assert len(e) == 0 and list(e.items()) == [] and not e
+
+
+def test_native_wav_reader_equals_loadWAV(tmp_path):
+    """sugar_wav_probe / sugar_wav_load (the host feed's reader for evaluation lists of 16-bit PCM files) against
+    loadWAV in eval mode, sample for sample: short files (wrap padding to 48 001), exactly 48 000, long ones, whole
+    utterances and linspace crops, a file with a LIST chunk in front of its data and one with an odd-sized chunk; other
+    formats are reported as such (the caller then keeps the Python loader)."""
+    import ctypes
+    import struct
+    from scipy.io import wavfile
+    from sugar_amd.waveforms import eval_segments, loadWAV
+    rng = np.random.default_rng(5)
+    sizes = [700, 16000, 47999, 48000, 48001, 50000, 123457, 320000]
+    paths = []
+    for i, n in enumerate(sizes):
+        p = str(tmp_path / ("u%d.wav" % i))
+        wavfile.write(p, 16000, rng.integers(-32768, 32768, size=n).astype(np.int16))
+        paths.append(p)
+    # a LIST chunk (odd size: padded to even) between fmt and data, as ffmpeg / sox write them
+    raw = open(paths[5], "rb").read()
+    k = raw.index(b"data")
+    extra = b"LIST" + struct.pack("<I", 7) + b"INFOabc" + b"\x00"
+    body = raw[:k] + extra + raw[k:]
+    body = body[:4] + struct.pack("<I", len(body) - 8) + body[8:]
+    p = str(tmp_path / "with_list.wav")
+    open(p, "wb").write(body)
+    paths.append(p)
+    sizes.append(sizes[5])
+    assert (wavfile.read(p)[1] == wavfile.read(paths[5])[1]).all()
+    n = len(paths)
+    lib = _lib.lib()
+    arr = (ctypes.c_char_p * n)(*[os.fsencode(q) for q in paths])
+    size, off = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+    _lib.check(lib.sugar_wav_probe(arr, n, 16000, size.ctypes.data, off.ctypes.data, 3), "sugar_wav_probe")
+    assert size.tolist() == sizes
+    for num_samples, num_eval in ((0, 1), (48000, 6), (32000, 10), (16000, 1)):
+        starts, lengths = eval_segments(size, num_samples, num_eval)
+        n_seg = starts.shape[1]
+        f_idx = np.repeat(np.arange(n, dtype=np.int32), n_seg)
+        s_len = np.repeat(lengths, n_seg)
+        s_start = np.ascontiguousarray(starts.reshape(-1))
+        for threads in (1, 5):
+            dst = np.full(int(s_len.sum()), np.nan, dtype=np.float32)
+            _lib.check(lib.sugar_wav_load(arr, size.ctypes.data, off.ctypes.data, f_idx.ctypes.data, s_start.ctypes.data,
+                                          s_len.ctypes.data, len(f_idx), dst.ctypes.data, threads), "sugar_wav_load")
+            want = np.concatenate([loadWAV(q, num_samples, True, num_eval).reshape(-1) for q in paths])
+            assert dst.shape == want.shape and (dst == want).all(), (num_samples, num_eval, threads)
+    # other formats: stereo, 8 kHz, float32 -> -1 (not an error); a missing file -> an error
+    others = []
+    for name, rate, data in (("stereo", 16000, rng.integers(-9, 9, size=(4000, 2)).astype(np.int16)),
+                             ("8k", 8000, rng.integers(-9, 9, size=4000).astype(np.int16)),
+                             ("f32", 16000, rng.standard_normal(4000).astype(np.float32))):
+        q = str(tmp_path / (name + ".wav"))
+        wavfile.write(q, rate, data)
+        others.append(q)
+    arr2 = (ctypes.c_char_p * 3)(*[os.fsencode(q) for q in others])
+    s2, o2 = np.empty(3, dtype=np.int64), np.empty(3, dtype=np.int64)
+    _lib.check(lib.sugar_wav_probe(arr2, 3, 16000, s2.ctypes.data, o2.ctypes.data, 2), "sugar_wav_probe")
+    assert s2.tolist() == [-1, -1, -1]
+    arr3 = (ctypes.c_char_p * 1)(os.fsencode(str(tmp_path / "missing.wav")))
+    assert lib.sugar_wav_probe(arr3, 1, 16000, s2.ctypes.data, o2.ctypes.data, 1) != 0
