@@ -245,6 +245,63 @@ def veri_validate(loader, model, args=None, tboard=None, norm=True, p_target=0.0
     return eer, dcf, vectors, scs
 
 
+class _BatchFeed:
+    """
+    Host batches of a DataLoader -> the device without stalling the forward that runs meanwhile: a batch in pageable host
+    memory is packed into one of three PINNED staging buffers (native multi-threaded copy, sugar_pack_segments) and
+    sent on a copy stream; the compute stream only waits for that copy's event.  `tensor.to(device)` from pageable memory
+    is a synchronous ~10 GB/s copy on the compute stream: 5 ms for a 256 x 3 s batch whose train-mode forward takes 1.8.
+    The recalibration steps themselves stay strictly in order on one stream (running statistics are updated step by step).
+    """
+    SLOTS = 3
+
+    def __init__(self, device):
+        self.device = device
+        self.pinned, self.dev = [None] * self.SLOTS, [None] * self.SLOTS
+        self.h2d = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.free = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.copy_stream = None
+        self.k, self.slot = 0, None
+
+    def to_device(self, inp):
+        self.slot = None
+        if inp.is_cuda or inp.numel() == 0:
+            return inp.to(self.device)
+        import ctypes
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream(self.device)
+        s, n = self.k % self.SLOTS, inp.numel()
+        if self.k >= self.SLOTS:
+            self.free[s].synchronize()                 # the forward that read this slot three batches ago has run
+        if self.pinned[s] is None or self.pinned[s].numel() < n:
+            self.pinned[s] = torch.empty(n, dtype=torch.float32, pin_memory=True)
+            self.dev[s] = torch.empty(n, dtype=torch.float32, device=self.device)
+            # the caching allocator may hand out memory that kernels already queued on the CURRENT stream still use
+            # (stream-ordered reuse); the copy stream writes into it, so it must run behind them
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        if inp.dtype == torch.float32 and inp.is_contiguous():
+            src = (ctypes.c_void_p * 1)(inp.data_ptr())
+            lens = (ctypes.c_int64 * 1)(n)
+            _lib.check(_lib.lib().sugar_pack_segments(src, lens, 1, self.pinned[s].data_ptr(), 8), "sugar_pack_segments")
+        else:
+            self.pinned[s][:n].copy_(inp.reshape(-1))
+        with torch.cuda.stream(self.copy_stream):
+            self.dev[s][:n].copy_(self.pinned[s][:n], non_blocking=True)
+            self.h2d[s].record(self.copy_stream)
+        torch.cuda.current_stream(self.device).wait_event(self.h2d[s])
+        self.slot = s
+        self.k += 1
+        return self.dev[s][:n].view(inp.shape)
+
+    def consumed(self):
+        """The forward reading the last batch has been enqueued on the current stream."""
+        if self.slot is not None:
+            self.free[self.slot].record(torch.cuda.current_stream(self.device))
+
+    def close(self):
+        torch.cuda.current_stream(self.device).synchronize()     # the staging buffers outlive the forwards that read them
+
+
 def batch_forward(loader, model, args=None, device="cuda:0"):
     """
     BN recalibration (sugar/models/__init__.py:201-242): forward the model in train() mode over `loader` so every
@@ -261,9 +318,12 @@ def batch_forward(loader, model, args=None, device="cuda:0"):
     with torch.no_grad():
         model.train()
         model.to(dev)
+        feed = _BatchFeed(dev)
         for batch in loader:
             inp = batch[0] if isinstance(batch, (list, tuple)) else batch
-            model.forward(inp.to(dev), None)
+            model.forward(feed.to_device(inp), None)
+            feed.consumed()
+        feed.close()
         model.train(origin_state)
     spk = model.module if hasattr(model, "module") else model
     sub = getattr(spk, "__S__", None)

@@ -289,6 +289,9 @@ class _HostFeed:
             cap = max(need, self.max_frames * 160)
             self.pinned[s] = torch.empty(cap, dtype=torch.float32, pin_memory=True)
             self.dev[s] = torch.empty(cap, dtype=torch.float32, device=self.device)
+            # the caching allocator may hand out memory that kernels already queued on the allocating (default) stream
+            # still use -- stream-ordered reuse; the copy stream writes into it, so it must run behind them
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def _pack(self, dst, segs):
         """All float32 contiguous host segments of the batch in ONE native call; anything else with tensor.copy_."""
