@@ -185,16 +185,22 @@ def score_cohorts(cohorts, vectors, mode="cosine", device="cuda:0"):
     dev = torch.device(device)
     if dev.type != "cuda":
         raise _lib.SugarError("sugar_amd runs on an MI355X only: pass device='cuda:N' (there is no CPU fallback)")
-    keys = list(vectors.keys())
-    seg = [0]
-    for k in keys:
-        seg.append(seg[-1] + vectors[k].reshape(-1, vectors[k].shape[-1]).shape[0])
-    vec = torch.cat([vectors[k].reshape(-1, vectors[k].shape[-1]).to(dev) for k in keys], dim=0).float().contiguous()
+    matrix = getattr(vectors, "matrix", None)
+    if matrix is not None and matrix.device == dev and len(vectors.files) == len(vectors):
+        # a VectorTable from extract_vectors (no file listed twice): its matrix and offsets as they are, instead of
+        # 4 874 views concatenated again
+        keys, vec, seg_off = list(vectors.files), matrix.float().contiguous(), vectors.seg_off
+    else:
+        keys = list(vectors.keys())
+        seg = [0]
+        for k in keys:
+            seg.append(seg[-1] + vectors[k].reshape(-1, vectors[k].shape[-1]).shape[0])
+        vec = torch.cat([vectors[k].reshape(-1, vectors[k].shape[-1]).to(dev) for k in keys], dim=0).float().contiguous()
+        seg_off = torch.tensor(seg, dtype=torch.int32, device=dev)
     coh = cohorts.to(dev).float().contiguous()
     n_utts, n_coh, dim = len(keys), coh.shape[0], vec.shape[1]
     if coh.shape[1] != dim:
         raise ValueError("cohort vectors have %d dimensions, utterance vectors %d" % (coh.shape[1], dim))
-    seg_off = torch.tensor(seg, dtype=torch.int32, device=dev)
     scratch = torch.empty((n_utts + n_coh) * dim, dtype=torch.float32, device=dev)
     out = torch.empty(n_utts, n_coh, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().sugar_cohort_scores(vec.data_ptr(), dim, seg_off.data_ptr(), n_utts, coh.data_ptr(), n_coh,
