@@ -147,7 +147,8 @@ def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transfor
     fb = transform if transform is not None else LogMelFbanks()
     # the evaluation list is walked and staged on the GPU once for all subnets
     bs = int(veri_loader.batch_size)                   # (1 = the reference's whole-utterance mode: the packer chooses)
-    packed = PackedUtterances(veri_loader.dataset.utterances, dev, batch_size=bs if bs > 1 else AUTO_BATCH)
+    packed = PackedUtterances(veri_loader.dataset.utterances, dev, batch_size=bs if bs > 1 else AUTO_BATCH,
+                              cache_features=transform is None or isinstance(transform, LogMelFbanks))
     veri_loader = _LoaderView(veri_loader, _TrialSnapshot(veri_loader.dataset))     # trial list parsed once
     results = {}
     # subnets cloned + packed ahead on host threads: True = 2 (one ahead left the launching thread waiting 6 ms per subnet

@@ -164,8 +164,14 @@ class PackedUtterances:
     dataset (4 874 __getitem__ calls, ~45 ms) once instead of per subnet.
     """
 
-    def __init__(self, datalst, device="cuda:0", batch_size=256, max_frames=262144, n_jobs=8):
+    def __init__(self, datalst, device="cuda:0", batch_size=256, max_frames=262144, n_jobs=8, cache_features=False):
+        """cache_features: keep the front-end's output (log-mel features, [frames, 80] in the model's compute dtype, a
+        quarter of the waveforms' bytes) of every batch after the first extract_vectors call and feed later calls --
+        other models over the same list -- from it: the front-end does not depend on the model, and in a NAS sweep it
+        was a tenth of every sampled subnet's GPU time."""
         from .transforms import BatchPlan
+        self.cache_features = bool(cache_features)
+        self._features = {}                            # torch dtype -> list of [R, 80] tensors, one per batch
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.SugarError("sugar_amd runs on an MI355X only: pass device='cuda:N' (there is no CPU fallback)")
@@ -204,6 +210,28 @@ class PackedUtterances:
 
     def __len__(self):
         return len(self.files)
+
+    def features(self, transform, dtype):
+        """The cached front-end output of every batch in `dtype` (computed on the current stream at the first call)."""
+        if dtype not in self._features:
+            self._features[dtype] = [transform.rows(flat, plan, dtype) for _, flat, plan in self.batches]
+        return self._features[dtype]
+
+    def embed(self, spk, sub, k, normalize, feats=None):
+        """Batch k through `sub` on the current stream: from the cached features when there are any, else the fused
+        waveform -> embedding call."""
+        idx, flat, plan = self.batches[k]
+        if feats is not None:
+            return sub.forward_rows(feats[k], plan.row_off, plan.B, plan.R, plan.t_max, normalize=normalize)
+        return spk._embed_flat(sub, flat, plan, normalize)
+
+
+def _packed_features(packed, spk, sub):
+    """The feature cache of a packed list for this model, or None (cache off, train mode, or not the fused front-end)."""
+    from .transforms import LogMelFbanks
+    if not packed.cache_features or sub.training or not isinstance(getattr(spk, "__T__", None), LogMelFbanks):
+        return None
+    return packed.features(spk.__T__, torch.bfloat16 if sub.precision == "bf16" else torch.float32)
 
 
 def _walk(datalst, n_jobs):
@@ -551,9 +579,13 @@ def extract_vectors(model, datalst, norm=True, device="cuda:0", n_jobs=4, batch_
         files, counts = packed.files, packed.counts
         out = torch.empty(packed.n_rows, 192, dtype=torch.float32, device=device)
         sub = spk._subnet()
+        feats = _packed_features(packed, spk, sub)     # (computed on `main` at the first call: before the lanes wait for it)
+        if feats is not None:
+            for lane in lanes:
+                lane.wait_stream(main)
         for k, (idx, flat, plan) in enumerate(packed.batches):
             with torch.cuda.stream(lanes[k % len(lanes)]):
-                out[idx] = spk._embed_flat(sub, flat, plan, bool(norm))
+                out[idx] = packed.embed(spk, sub, k, bool(norm), feats)
     elif len(datalst) and not _segments(datalst[0])[0].is_cuda:
         # host-resident list (files, or tensors in host memory): streamed -- items read ahead by n_jobs threads, pinned
         # triple-buffered staging on a copy stream, the GPU starts on the first chunk (_HostFeed)
@@ -632,9 +664,8 @@ def _extract_sharded(model, datalst, norm, device, n_jobs, batch_size, max_frame
         share = [[k for k in range(len(packed.batches)) if k % world == r] for r in range(world)]
         parts = []
         for j, k in enumerate(share[rank]):
-            idx, flat, plan = packed.batches[k]
             with torch.cuda.stream(lanes[j % len(lanes)]):
-                parts.append(spk._embed_flat(sub, flat, plan, bool(norm)))
+                parts.append(packed.embed(spk, sub, k, bool(norm)))
         for lane in lanes:
             main.wait_stream(lane)
         local = torch.cat(parts) if parts else torch.empty(0, 192, dtype=torch.float32, device=device)
