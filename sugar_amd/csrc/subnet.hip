@@ -649,7 +649,9 @@ int sugar_subnet_create(const SugarSubnetDesc* d, int dtype, int device, SugarSu
   n->device = device;
   int rc;
   {
-    ArenaScope scope(&n->arena);                       // all packed tensors into the subnet's chunks, sent in one go
+    // all packed tensors into the subnet's chunks, sent in one go (SUGAR_NO_ARENA: one hipMalloc + hipMemcpy per tensor
+    // as before, for A/B runs)
+    ArenaScope scope(getenv("SUGAR_NO_ARENA") ? nullptr : &n->arena);
     rc = create(d, dtype, n);
   }
   if (!rc) rc = arena_flush(&n->arena);
