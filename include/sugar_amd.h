@@ -226,7 +226,7 @@ int sugar_pack_segments(const float* const* h_src, const int64_t* h_len, int n, 
  * Which segments a file yields (padding floor, crop starts) stays on the Python side (sugar_amd/waveforms.py). */
 int sugar_wav_probe(const char* const* h_paths, int n, int sample_rate, int64_t* h_n_samples, int64_t* h_data_off,
                     int n_threads);
-int sugar_wav_load(const char* const* h_paths, const int64_t* h_n_samples, const int64_t* h_data_off,
+int sugar_wav_load(const char* const* h_paths, const int64_t* h_n_samples, const int64_t* h_data_off, int n_files,
                    const int32_t* h_seg_file, const int64_t* h_seg_start, const int64_t* h_seg_len, int n_segs,
                    float* h_dst, int n_threads);
 

@@ -61,7 +61,7 @@ SYMBOLS = {
     "sugar_norm2_trials": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
     "sugar_pack_segments": (_i, [_vp, _vp, _i, _vp, _i]),
     "sugar_wav_probe": (_i, [_vp, _i, _i, _vp, _vp, _i]),
-    "sugar_wav_load": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
+    "sugar_wav_load": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "sugar_cohort_scores": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "sugar_topk_stats": (_i, [_vp, _i64, _i, _i, C.c_float, _vp, _vp, _vp]),
     "sugar_snorm_trials": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, C.c_float, _vp, _vp]),

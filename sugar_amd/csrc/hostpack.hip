@@ -135,14 +135,17 @@ extern "C" int sugar_wav_probe(const char* const* h_paths, int n, int sample_rat
 // Segment j = h_seg_len[j] samples of file h_seg_file[j] from sample h_seg_start[j] on, continued periodically past the
 // file's end (np.pad(..., mode="wrap"), sugar/waveforms.py:94-98), written to h_dst one segment after the other.
 extern "C" int sugar_wav_load(const char* const* h_paths, const int64_t* h_n_samples, const int64_t* h_data_off,
-                              const int32_t* h_seg_file, const int64_t* h_seg_start, const int64_t* h_seg_len, int n_segs,
-                              float* h_dst, int n_threads) {
+                              int n_files, const int32_t* h_seg_file, const int64_t* h_seg_start, const int64_t* h_seg_len,
+                              int n_segs, float* h_dst, int n_threads) {
   using namespace sugar;
-  SUGAR_CHECK_ARG(h_paths && h_n_samples && h_data_off && h_seg_file && h_seg_start && h_seg_len && h_dst && n_segs > 0,
+  SUGAR_CHECK_ARG(h_paths && h_n_samples && h_data_off && h_seg_file && h_seg_start && h_seg_len && h_dst && n_segs > 0 &&
+                      n_files > 0,
                   "wav_load: bad arguments");
   std::vector<int64_t> off((size_t)n_segs + 1, 0);
   for (int j = 0; j < n_segs; ++j) {
-    SUGAR_CHECK_ARG(h_seg_len[j] >= 0 && h_seg_start[j] >= 0 && h_n_samples[h_seg_file[j]] > 0,
+    SUGAR_CHECK_ARG(h_seg_file[j] >= 0 && h_seg_file[j] < n_files, "wav_load: segment %d names file %d of %d", j,
+                    h_seg_file[j], n_files);
+    SUGAR_CHECK_ARG(h_seg_len[j] >= 0 && h_seg_start[j] >= 0 && h_n_samples[h_seg_file[j]] > 0 && h_paths[h_seg_file[j]],
                     "wav_load: segment %d has a bad range or an empty file", j);
     off[j + 1] = off[j] + h_seg_len[j];
   }

@@ -420,7 +420,7 @@ class _HostFeed:
                 b = np.asarray(batch, dtype=np.int64)
                 bf, bs, bl = np.ascontiguousarray(f_idx[b]), np.ascontiguousarray(s_start[b]), np.ascontiguousarray(s_len[b])
                 self._slot(s, int(bl.sum()))
-                _lib.check(_lib.lib().sugar_wav_load(arr, size.ctypes.data, off.ctypes.data, bf.ctypes.data, bs.ctypes.data,
+                _lib.check(_lib.lib().sugar_wav_load(arr, size.ctypes.data, off.ctypes.data, n, bf.ctypes.data, bs.ctypes.data,
                                                      bl.ctypes.data, len(batch), self.pinned[s].data_ptr(), self.workers),
                            "sugar_wav_load")
                 self.stats["load_s"] += time.perf_counter() - t1

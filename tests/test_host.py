@@ -266,10 +266,14 @@ def test_native_wav_reader_equals_loadWAV(tmp_path):
         s_start = np.ascontiguousarray(starts.reshape(-1))
         for threads in (1, 5):
             dst = np.full(int(s_len.sum()), np.nan, dtype=np.float32)
-            _lib.check(lib.sugar_wav_load(arr, size.ctypes.data, off.ctypes.data, f_idx.ctypes.data, s_start.ctypes.data,
+            _lib.check(lib.sugar_wav_load(arr, size.ctypes.data, off.ctypes.data, n, f_idx.ctypes.data, s_start.ctypes.data,
                                           s_len.ctypes.data, len(f_idx), dst.ctypes.data, threads), "sugar_wav_load")
             want = np.concatenate([loadWAV(q, num_samples, True, num_eval).reshape(-1) for q in paths])
             assert dst.shape == want.shape and (dst == want).all(), (num_samples, num_eval, threads)
+    bad = np.array([n], dtype=np.int32)                         # a segment naming a file past the list: refused
+    one = np.array([10], dtype=np.int64)
+    assert lib.sugar_wav_load(arr, size.ctypes.data, off.ctypes.data, n, bad.ctypes.data, one.ctypes.data, one.ctypes.data,
+                              1, dst.ctypes.data, 1) != 0
     # other formats: stereo, 8 kHz, float32 -> -1 (not an error); a missing file -> an error
     others = []
     for name, rate, data in (("stereo", 16000, rng.integers(-9, 9, size=(4000, 2)).astype(np.int16)),
