@@ -129,3 +129,41 @@ def test_native_file_feed_equals_python_loader(tmp_path):
             assert torch.equal(got[name], got["native"]), (num_samples, name)
         staged = sugar_amd.extract_vectors(model, u.stage("cuda:0", batch_size=3))
         assert torch.equal(staged.matrix, got["native"])
+
+
+@pytest.mark.gpu
+def test_streamed_feed_in_several_chunks_equals_one_chunk(tmp_path, monkeypatch):
+    """The host feed sorts and batches the list chunk by chunk (2^20 frames at a time, so that the GPU starts before the
+    list is read and host memory stays bounded).  With a chunk of 1 500 frames this 12-file list goes through in
+    several chunks -- other batch compositions, same row order: the table equals the one-chunk result (bit for bit: an
+    utterance's embedding does not depend on what it is batched with), for the native reader and for the Python loader."""
+    import sugar_amd.vectors as V
+    from scipy.io import wavfile
+    root = str(tmp_path)
+    rng = np.random.default_rng(11)
+    names = []
+    for i, n in enumerate(rng.integers(20000, 90000, size=12)):         # 1.25 .. 5.6 s (the short ones wrap-padded to 3 s)
+        names.append("c%02d.wav" % i)
+        wavfile.write(os.path.join(root, names[-1]), 16000, (rng.standard_normal(n) * 2000).astype(np.int16))
+    u = Utterance(names, num_samples=0, mode_eval=True, num_eval=1, root_dir=root)
+
+    class PyUtterance(Utterance):
+        pass
+
+    py = PyUtterance(u.datalst, u.num_samples, u.mode_eval, u.num_eval, u.root_dir)
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    sub = sup.clone(layout.SMALLEST).set_precision("bf16")
+    model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).cuda().eval()
+    want = sugar_amd.extract_vectors(model, u, device="cuda:0", batch_size=4)
+    calls = []
+    orig = sugar_amd.SpeakerModel._embed_flat
+    monkeypatch.setattr(sugar_amd.SpeakerModel, "_embed_flat",
+                        lambda self, s, flat, plan, nrm: (calls.append(plan.B), orig(self, s, flat, plan, nrm))[1])
+    monkeypatch.setattr(V._HostFeed, "CHUNK_FRAMES", 1500)
+    for data in (u, py):
+        del calls[:]
+        got = sugar_amd.extract_vectors(model, data, device="cuda:0", batch_size=4, n_jobs=2)
+        assert sum(calls) == len(u) and len(calls) > -(-len(u) // 4)          # more, smaller batches than one chunk gives
+        assert list(got.keys()) == list(want.keys())
+        assert torch.equal(got.matrix, want.matrix)
