@@ -139,3 +139,25 @@ def test_conv_epilogue_statistics_equal_the_separate_pass(precision, wreg_min_r)
     assert _rel(out[0][0], out[1][0]) < 50 * loose
     for k in out[0][1]:
         assert _rel(out[0][1][k].numpy(), out[1][1][k].numpy()) < (tight if k.startswith(first) else loose), k
+
+
+@pytest.mark.gpu
+def test_batch_forward_host_batches_equal_resident_batches():
+    """batch_forward stages DataLoader batches from pageable host memory through three pinned slots and a copy stream
+    (models._BatchFeed); seven batches reuse every slot at least twice.  Running statistics are bit-equal to the same
+    batches already on the GPU, for float32 batches, for a batch the feed must convert (float64) and a [B, 1, L] one."""
+    dev = torch.device("cuda", 0)
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    host = [synth.waveforms(5, 20000 + 1600 * i, seed=60 + i) for i in range(7)]
+    host[2] = host[2].double()
+    host[4] = host[4].unsqueeze(1)
+    stats = {}
+    for name, loader in (("resident", [(b.to(dev),) for b in host]), ("host", [(b,) for b in host])):
+        sub = sup.clone(layout.SMALLEST).set_precision("bf16")
+        model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+        sugar_amd.batch_forward(loader, model, device="cuda:0")
+        stats[name] = {k: v.clone() for k, v in sub.state_dict().items() if "running" in k or "tracked" in k}
+    assert int(stats["host"]["layer1.bn.num_batches_tracked"]) == 7
+    for k in stats["host"]:
+        assert torch.equal(stats["host"][k], stats["resident"][k]), k
