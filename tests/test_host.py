@@ -288,3 +288,41 @@ def test_native_wav_reader_equals_loadWAV(tmp_path):
     assert s2.tolist() == [-1, -1, -1]
     arr3 = (ctypes.c_char_p * 1)(os.fsencode(str(tmp_path / "missing.wav")))
     assert lib.sugar_wav_probe(arr3, 1, 16000, s2.ctypes.data, o2.ctypes.data, 1) != 0
+
+
+def test_dataset_walk_keeps_order_and_surfaces_loader_errors():
+    """vectors._walk: items in list order whether they are loaded in line (cheap items: an in-memory list) or by loader
+    threads running ahead (slow items: files); an exception in a loader thread reaches the consumer; abandoning the
+    walk half way does not hang."""
+    import time
+    from sugar_amd.vectors import _walk
+
+    class Data:
+        def __init__(self, n, delay, bad=None):
+            self.n, self.delay, self.bad, self.seen = n, delay, bad, []
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            if self.delay:
+                time.sleep(self.delay)
+            if i == self.bad:
+                raise OSError("cannot read item %d" % i)
+            self.seen.append(i)
+            return {"file": "f%d" % i, "input": torch.zeros(1, 300)}
+
+    for delay, jobs in ((0, 8), (0.002, 8), (0.002, 1), (0, 1)):
+        d = Data(150, delay)
+        t0 = time.perf_counter()
+        assert [it["file"] for it in _walk(d, jobs)] == ["f%d" % i for i in range(150)]
+        if delay and jobs > 1:
+            assert time.perf_counter() - t0 < 150 * delay * 0.6        # really in parallel
+    with pytest.raises(OSError, match="item 97"):
+        list(_walk(Data(150, 0.002, bad=97), 8))
+    d = Data(400, 0.002)
+    for k, it in enumerate(_walk(d, 8)):
+        if k == 20:
+            break                                                     # the generator is closed: its pool shuts down
+    assert len(d.seen) < 200
+    assert list(_walk(Data(0, 0), 4)) == [] and len(list(_walk(Data(3, 0), 4))) == 3
