@@ -12,6 +12,9 @@ import sugar_amd  # noqa: E402
 from sugar_amd import layout, synth  # noqa: E402
 
 N_SUB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if os.environ.get("SWEEP_LANES"):                 # A/B: HIP streams that consecutive batches of one extraction alternate over
+    import sugar_amd.vectors
+    sugar_amd.vectors.N_LANES = int(os.environ["SWEEP_LANES"])
 N_UTT, N_TRIALS = 4874, 37720
 dev = torch.device("cuda", 0)
 sup = sugar_amd.tdnn8m2g()
