@@ -155,6 +155,7 @@ class TDNNSubnet(nn.Module):
         self._workspace = {}     # (device index, stream) -> torch.uint8 tensor
         self._device = torch.device("cpu")
         self._bn_dirty = None    # (device index, dtype) of the handle holding recalibrated, not yet synced statistics
+        self._bn_unread = None   # ... folded into the eval path already, but not yet copied into this module's buffers
         self._bn_batches = 0
         self._generation = 0     # bumped whenever device pointers handed out earlier become invalid (release, precision)
         # parameters changed (also via a parent's load_state_dict) -> drop the packed device copies
@@ -217,7 +218,7 @@ class TDNNSubnet(nn.Module):
             _lib.lib().sugar_subnet_destroy(h)
         self._handles = {}
         self._workspace = {}
-        self._bn_dirty, self._bn_batches = None, 0
+        self._bn_dirty, self._bn_unread, self._bn_batches = None, None, 0
 
     def drop_workspaces(self):
         """Give the per-(device, stream) workspaces back to torch's allocator (no device synchronisation; the packed
@@ -347,19 +348,26 @@ class TDNNSubnet(nn.Module):
     def mark_recalibrated(self, device):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, self.dtype_id)
-        if self._bn_dirty not in (None, key):
+        if self._bn_dirty not in (None, key) or self._bn_unread not in (None, key):
             raise _lib.SugarError("BN recalibration is in progress on another device / precision: call sync_bn() first")
         self._bn_dirty = key
         self._bn_batches += 1
 
-    def sync_bn(self):
+    def sync_bn(self, read_back=True):
         """Fold the recalibrated running statistics into the eval path and copy them into this module's buffers
-        (what `model.eval()` / `bn_state_dict` see in the reference).  No-op when nothing was recalibrated."""
-        if self._bn_dirty is None:
+        (what `model.eval()` / `bn_state_dict` see in the reference).  No-op when nothing was recalibrated.
+        read_back=False: fold only -- the eval path is current, the module's buffers are NOT (30 small blocking copies
+        and their bookkeeping, ~2 ms during which the GPU idles); for callers that evaluate the subnet and throw it away
+        (the NAS sweep).  A later sync_bn() / state_dict() still brings the buffers up to date."""
+        if self._bn_dirty is None and self._bn_unread is None:
             return self
-        key, self._bn_dirty = self._bn_dirty, None
+        if self._bn_dirty is not None:
+            self._bn_unread, self._bn_dirty = self._bn_dirty, None
+            _lib.check(_lib.lib().sugar_subnet_bn_commit(self._handles[self._bn_unread]), "sugar_subnet_bn_commit")
+        if not read_back:
+            return self
+        key, self._bn_unread = self._bn_unread, None
         h = self._handles[key]
-        _lib.check(_lib.lib().sugar_subnet_bn_commit(h), "sugar_subnet_bn_commit")
         buffers = dict(self.named_buffers())
         params = dict(self.named_parameters())
         for i, name in enumerate(self.bn_names()):
@@ -381,7 +389,7 @@ class TDNNSubnet(nn.Module):
 
     def reset_bn(self):
         """nn.BatchNorm1d.reset_running_stats on every BN (running_mean 0, running_var 1, num_batches_tracked 0)."""
-        self._bn_dirty, self._bn_batches = None, 0
+        self._bn_dirty, self._bn_unread, self._bn_batches = None, None, 0
         with torch.no_grad():
             for k, t in list(self.named_buffers()) + list(self.named_parameters()):
                 if k.endswith("running_mean"):
@@ -393,9 +401,18 @@ class TDNNSubnet(nn.Module):
         self.release()
         return self
 
+    bn_lazy = False          # True: recalibrated statistics are folded into the eval path but copied into this module's
+                             # buffers only when someone asks for them (state_dict, sync_bn(), another precision / device)
+
     def eval_handle(self, device=None):
         """Handle for the eval-mode entry points: recalibrated statistics are folded in first."""
-        self.sync_bn()
+        if self._bn_dirty is not None:
+            self.sync_bn(read_back=not self.bn_lazy)
+        if self._bn_unread is not None:
+            dev = self._device if device is None else torch.device(device)
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            if (idx, self.dtype_id) != self._bn_unread:
+                self.sync_bn()                         # another handle is asked for: it is packed from the buffers
         return self.handle(device)
 
     def state_dict(self, *args, **kwargs):

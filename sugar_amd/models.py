@@ -328,5 +328,5 @@ def batch_forward(loader, model, args=None, device="cuda:0"):
     spk = model.module if hasattr(model, "module") else model
     sub = getattr(spk, "__S__", None)
     if isinstance(sub, TDNNSubnet):
-        sub.sync_bn()
+        sub.sync_bn(read_back=not sub.bn_lazy)
     return model

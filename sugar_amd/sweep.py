@@ -54,6 +54,7 @@ def _prepare(supernet, config, precision, dev):
     cfg, state = supernet.materialize(config)
     sub = TDNNSubnet(cfg, state, supernet.in_feats, supernet.out_embeds, precision, adopt=True)
     sub.to(dev)
+    sub.bn_lazy = True                                 # evaluated and thrown away: nobody reads its buffers after recalibration
     sub.handle(dev)                                    # sugar_subnet_create: fold BN, pack, upload
     return sub
 

@@ -161,3 +161,32 @@ def test_batch_forward_host_batches_equal_resident_batches():
     assert int(stats["host"]["layer1.bn.num_batches_tracked"]) == 7
     for k in stats["host"]:
         assert torch.equal(stats["host"][k], stats["resident"][k]), k
+
+
+@pytest.mark.gpu
+def test_lazy_bn_read_back_changes_nothing_but_when_the_buffers_are_read():
+    """TDNNSubnet.bn_lazy (the NAS sweep sets it on the subnets it evaluates and throws away): after recalibration the
+    statistics are folded into the eval path at once, the module's buffers are brought up to date only when someone asks
+    (state_dict, another precision).  Eval embeddings and the final state dict are bit-equal to the eager mode."""
+    dev = torch.device("cuda", 0)
+    sup = sugar_amd.tdnn8m2g()
+    sup.load_state_dict(synth.fill_state_dict(layout.supernet_shapes(), seed=0))
+    loader = [(synth.waveforms(5, 24000, seed=70 + i),) for i in range(3)]
+    wav = synth.waveforms(3, 20000, seed=9).to(dev)
+    got = {}
+    for lazy in (False, True):
+        sub = sup.clone(layout.SMALLEST).set_precision("bf16")
+        sub.bn_lazy = lazy
+        model = sugar_amd.WrappedModel(sugar_amd.SpeakerModel(sub, transform=sugar_amd.LogMelFbanks())).to(dev).eval()
+        before = float(sub.layer1.bn.running_mean.abs().sum())
+        sugar_amd.batch_forward(loader, model, device="cuda:0")
+        emb = model(wav).clone()
+        stale = float(sub.layer1.bn.running_mean.abs().sum()) == before      # buffers untouched so far?
+        assert stale == lazy
+        sd = {k: v.clone() for k, v in sub.state_dict().items()}            # asks for the buffers
+        assert float(sub.layer1.bn.running_mean.abs().sum()) != before
+        emb32 = model.module.__S__.set_precision("fp32") and model(wav).clone()   # another handle, packed from the buffers
+        got[lazy] = (emb, sd, emb32)
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][2], got[False][2])
+    for k in got[False][1]:
+        assert torch.equal(got[True][1][k], got[False][1][k]), k
