@@ -44,7 +44,7 @@ class Loader:
 lab, a, b = synth.trial_pairs(N_UTT, N_TRIALS, seed=1)
 trials = Trials({"label": int(lab[i]), "enroll": "utt%04d.wav" % a[i], "test": "utt%04d.wav" % b[i]} for i in range(N_TRIALS))
 trials.utterances = Utts()
-loader = Loader(trials, 256)
+loader = Loader(trials, int(os.environ.get("SWEEP_BATCH", "256")))      # utterances per packed call (A/B)
 recal = None
 if os.environ.get("SWEEP_RECAL"):      # the full NAS loop: BN recalibration over 24 x 256 x 3 s utterances before every evaluation
     rw = torch.randn(24, 256, 48000, device=dev)
