@@ -129,7 +129,9 @@ def evaluate_subnets(supernet, configs, veri_loader, recal_loader=None, transfor
 
     Returns {config_key: {"eer": .., "eer_thresh": .., "mindcf": .., "mindcf_thresh": .., "rank": ..}} for ALL configs
     on every rank when `gather` (one all_gather_object), else for this rank's share.  `rank` / `world` default to
-    torch.distributed's when it is initialised, else 0 / 1.  `on_result(config, result)` is called as results arrive.
+    torch.distributed's when it is initialised, else 0 / 1.  `on_result(config, result)` is called as results arrive
+    (one subnet behind the GPU: the metrics of subnet i - 1 are computed while subnet i runs).
+    `prefetch`: subnets cloned and packed ahead on host threads (True: 2, an int: that many, False / 0: none).
     `timings`: a dict that receives the launching thread's seconds per phase (diagnostics, tools/sweep_bench.py).
     """
     if not isinstance(supernet, DynamicTDNN):
